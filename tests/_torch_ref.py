@@ -1,0 +1,59 @@
+"""Independent torch-CPU autograd statement of ContextSkipNew (arm_shaping.py:1272-1354), used
+only to cross-check the numpy oracle.  It shares NO code with
+oracle/ctx_oracle.py: convs go through torch's own conv2d / conv_transpose2d with TF's SAME
+semantics emulated by explicit pad / crop, and gradients come from autograd."""
+import torch
+import torch.nn.functional as F
+
+
+def lrelu(x):
+    return torch.maximum(x, 0.2 * x)
+
+
+def tf_conv(x_nhwc, w_hwio, b):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    H, W = x.shape[2:]
+    assert H % 2 == 0 and W % 2 == 0
+    x = F.pad(x, (1, 2, 1, 2))                       # SAME, k=5, s=2, even input: (1, 2)
+    y = F.conv2d(x, w_hwio.permute(3, 2, 0, 1), b, stride=2)
+    return y.permute(0, 2, 3, 1)
+
+
+def tf_deconv(x_nhwc, w_hwoi, b):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    h, w = x.shape[2:]
+    # torch conv_transpose2d weight is [in, out, kh, kw]; TF's is [kh, kw, out, in]
+    full = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=2, padding=0)
+    y = full[:, :, 1:1 + 2 * h, 1:1 + 2 * w] + b.view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1)
+
+
+def forward(p, src, ctx, tgt, H, W, gf):
+    def enc(scope, img, z_lrelu):
+        acts, h = [], img
+        for k in range(4):
+            h = lrelu(tf_conv(h, p[f"{scope}/h{k}_conv/w"], p[f"{scope}/h{k}_conv/biases"]))
+            acts.append(h)
+        h4 = lrelu(h.reshape(h.shape[0], -1) @ p[f"{scope}/h4_lin/Matrix"] + p[f"{scope}/h4_lin/bias"])
+        z = h4 @ p[f"{scope}/hz_lin/Matrix"] + p[f"{scope}/hz_lin/bias"]
+        return acts, (lrelu(z) if z_lrelu else z)
+
+    def dec(z, skips):
+        h = lrelu(z @ p["deconv/d_h0_lin/Matrix"] + p["deconv/d_h0_lin/bias"]).reshape(-1, H // 16, W // 16, 8 * gf)
+        for k in range(1, 5):
+            h = tf_deconv(torch.cat([h, skips[4 - k]], 3), p[f"deconv/d_h{k}/w"], p[f"deconv/d_h{k}/biases"])
+            if k < 4:
+                h = lrelu(h)
+        return h
+
+    skips, ctx_z = enc("conv_context", ctx, False)
+    _, src_z = enc("conv", src, True)
+    _, tgt_z = enc("conv", tgt, True)
+    th0 = lrelu(torch.cat([src_z, ctx_z], 1) @ p["translate/trans_h0/Matrix"] + p["translate/trans_h0/bias"])
+    trans_z = th0 @ p["translate/trans_z/Matrix"] + p["translate/trans_z/bias"]
+    out, out2 = dec(trans_z, skips), dec(tgt_z, skips)
+    sim = ((trans_z - tgt_z) ** 2).mean() * 1e3
+    r1 = 0.5 * ((tgt - out) ** 2).sum()
+    r2 = 0.5 * ((tgt - out2) ** 2).sum()
+    return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1,
+                recon2=r2, loss=r1 + r2 + sim)
