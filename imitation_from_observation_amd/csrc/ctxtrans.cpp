@@ -1,0 +1,805 @@
+// ctxtrans.cpp -- host side of libctxtrans.so: handle, HBM layout, the forward / backward / Adam
+// launch sequence of ContextSkipNew (gym/envs/mujoco/arm_shaping.py:1272-1354) and the C ABI of
+// include/ctxtrans.h.  There is no CPU code path: every contraction runs in the HIP kernels of
+// igemm.h / kernels.hip; without a device ctx_create fails.
+//
+// Batching (what makes each filter gradient a single launch): the `conv` encoder runs once on the
+// stacked [tgt | src] frames (2B), the decoder once on the stacked [translated | truth] codes (2B)
+// with the ctx skips indexed img % B; `conv_context` runs on B.
+//
+// HBM layout per handle
+//   arena   [params | grads | adam_m | adam_v], each Ppad floats (P rounded up to 64)
+//   img     [tgt | src | ctx] f32 frames, 3B x H x W x 3
+//   Z       [trans_z | tgt_z | src_z] codes, 3B x F  -> decoder input = first 2B rows,
+//           `conv` encoder output = last 2B rows, no copies
+//   dZ      same rows for the code gradients
+//   one buffer per activation and per activation gradient (NHWC), sized for max_batch
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/ctxtrans.h"
+#include "launch.h"
+
+using namespace ctx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int64_t shape[4];
+    int64_t offset;
+    int64_t size;
+};
+
+}  // namespace
+
+struct ctx_handle {
+    ctx_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float* arena = nullptr;
+    bool own_arena = false;
+    int64_t P = 0, Ppad = 0;
+    std::vector<ParamInfo> params;
+    std::vector<void*> allocs;
+    std::string err;
+    int64_t adam_t = 0;
+    int last_B = 0;
+    bool have_grads = false;
+
+    // dims
+    int H, W, d, F, Bm;
+    int hh[5], ww[5];   // hh[k] = H >> k
+    int64_t npi;        // H*W*3
+    int64_t D0;         // d_h0_lin width = 8d * h16 * w16
+
+    // buffers (see header comment)
+    uint8_t* u8 = nullptr;
+    float *img = nullptr, *Z = nullptr, *dZ = nullptr;
+    float *s[5] = {}, *c[5] = {}, *cz = nullptr, *th0 = nullptr;     // s[k], c[k]: h0..h3 conv outputs, [4] = h4
+    float *dz = nullptr, *e[4] = {}, *out = nullptr;                 // e[1..3] decoder activations
+    float *dout = nullptr, *dE[4] = {}, *dSk[4] = {}, *dDz = nullptr, *dsim2 = nullptr;
+    float *dth0 = nullptr, *dcz = nullptr, *dS[5] = {}, *dC[5] = {};
+    float *scratch = nullptr, *slab = nullptr, *scalars = nullptr;
+    int64_t slab_floats = 0;
+
+    float* Wp(const char* name) const { return arena + find(name); }
+    float* Gp(const char* name) const { return arena + Ppad + find(name); }
+    int64_t find(const char* name) const {
+        for (auto& p : params)
+            if (p.name == name) return p.offset;
+        return -1;
+    }
+};
+
+namespace {
+
+int fail(ctx_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(h, CTX_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int check_cfg(const ctx_config* c, ctx_handle* h) {
+    if (!c) return fail(h, CTX_E_INVALID, "cfg is NULL");
+    if (c->variant != CTX_VARIANT_SKIPNEW) return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
+    if (c->C != 3) return fail(h, CTX_E_INVALID, "C must be 3");
+    if (c->H <= 0 || c->W <= 0 || c->H % 16 || c->W % 16)
+        return fail(h, CTX_E_INVALID, "H, W must be positive multiples of 16 (got %dx%d)", c->H, c->W);
+    if (c->df_dim <= 0 || c->df_dim % 32) return fail(h, CTX_E_INVALID, "df_dim must be a multiple of 32");
+    if (c->featsize <= 0 || c->featsize % 32) return fail(h, CTX_E_INVALID, "featsize must be a multiple of 32");
+    if (c->max_batch <= 0) return fail(h, CTX_E_INVALID, "max_batch must be positive");
+    return CTX_OK;
+}
+
+// TF variable inventory in arena order (names: SURVEY.md section 5; shapes: arm_shaping.py:24-29,
+// 51-55, 66-79, 1282-1343)
+void build_params(const ctx_config& c, std::vector<ParamInfo>& out, int64_t& total) {
+    const int64_t d = c.df_dim, F = c.featsize, h16 = c.H / 16, w16 = c.W / 16;
+    int64_t off = 0;
+    auto add = [&](const std::string& name, std::vector<int64_t> shp) {
+        ParamInfo p;
+        p.name = name;
+        p.ndim = (int)shp.size();
+        p.size = 1;
+        for (int i = 0; i < 4; ++i) {
+            p.shape[i] = i < p.ndim ? shp[i] : 1;
+            p.size *= p.shape[i];
+        }
+        p.offset = off;
+        off += p.size;
+        out.push_back(p);
+    };
+    auto enc = [&](const std::string& sc) {
+        int64_t cin = c.C;
+        const int64_t couts[4] = {d, 2 * d, 4 * d, 8 * d};
+        for (int k = 0; k < 4; ++k) {
+            add(sc + "/h" + std::to_string(k) + "_conv/w", {5, 5, cin, couts[k]});
+            add(sc + "/h" + std::to_string(k) + "_conv/biases", {couts[k]});
+            cin = couts[k];
+        }
+        add(sc + "/h4_lin/Matrix", {h16 * w16 * 8 * d, F});
+        add(sc + "/h4_lin/bias", {F});
+        add(sc + "/hz_lin/Matrix", {F, F});
+        add(sc + "/hz_lin/bias", {F});
+    };
+    enc("conv_context");
+    enc("conv");
+    add("translate/trans_h0/Matrix", {2 * F, F});
+    add("translate/trans_h0/bias", {F});
+    add("translate/trans_z/Matrix", {F, F});
+    add("translate/trans_z/bias", {F});
+    add("deconv/d_h0_lin/Matrix", {F, 8 * d * h16 * w16});
+    add("deconv/d_h0_lin/bias", {8 * d * h16 * w16});
+    add("deconv/d_h1/w", {5, 5, 4 * d, 16 * d});
+    add("deconv/d_h1/biases", {4 * d});
+    add("deconv/d_h2/w", {5, 5, 2 * d, 8 * d});
+    add("deconv/d_h2/biases", {2 * d});
+    add("deconv/d_h3/w", {5, 5, d, 4 * d});
+    add("deconv/d_h3/biases", {d});
+    add("deconv/d_h4/w", {5, 5, c.C, 2 * d});
+    add("deconv/d_h4/biases", {c.C});
+    total = off;
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+template <class T>
+int dev_alloc(ctx_handle* h, T** p, int64_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, (size_t)count * sizeof(T));
+    if (e != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%lld bytes): %s", (long long)(count * sizeof(T)), hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return CTX_OK;
+}
+
+#define TRY(expr)              \
+    do {                       \
+        int r_ = (expr);       \
+        if (r_ != CTX_OK) return r_; \
+    } while (0)
+
+int alloc_buffers(ctx_handle* h) {
+    const int64_t B = h->Bm, d = h->d, F = h->F;
+    TRY(dev_alloc(h, &h->u8, 3 * B * h->npi));
+    TRY(dev_alloc(h, &h->img, 3 * B * h->npi));
+    TRY(dev_alloc(h, &h->Z, 3 * B * F));
+    TRY(dev_alloc(h, &h->dZ, 3 * B * F));
+    for (int k = 0; k < 4; ++k) {
+        const int64_t pix = (int64_t)h->hh[k + 1] * h->ww[k + 1], ch = d << k;
+        TRY(dev_alloc(h, &h->s[k], 2 * B * pix * ch));
+        TRY(dev_alloc(h, &h->dS[k], 2 * B * pix * ch));
+        TRY(dev_alloc(h, &h->c[k], B * pix * ch));
+        TRY(dev_alloc(h, &h->dC[k], B * pix * ch));
+        TRY(dev_alloc(h, &h->dSk[k], 2 * B * pix * ch));   // d loss / d (ctx skip h_k), per decoder pass
+    }
+    TRY(dev_alloc(h, &h->s[4], 2 * B * F));
+    TRY(dev_alloc(h, &h->dS[4], 2 * B * F));
+    TRY(dev_alloc(h, &h->c[4], B * F));
+    TRY(dev_alloc(h, &h->dC[4], B * F));
+    TRY(dev_alloc(h, &h->cz, B * F));
+    TRY(dev_alloc(h, &h->dcz, B * F));
+    TRY(dev_alloc(h, &h->th0, B * F));
+    TRY(dev_alloc(h, &h->dth0, B * F));
+    TRY(dev_alloc(h, &h->dsim2, 2 * B * F));
+    TRY(dev_alloc(h, &h->dz, 2 * B * h->D0));
+    TRY(dev_alloc(h, &h->dDz, 2 * B * h->D0));
+    for (int k = 1; k <= 3; ++k) {   // e[k]: output of d_hk, spatial H >> (4-k), channels 8d >> k
+        const int64_t pix = (int64_t)h->hh[4 - k] * h->ww[4 - k], ch = (8 * d) >> k;
+        TRY(dev_alloc(h, &h->e[k], 2 * B * pix * ch));
+        TRY(dev_alloc(h, &h->dE[k], 2 * B * pix * ch));
+    }
+    TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
+    TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
+    int64_t maxc = std::max<int64_t>(h->D0, F);
+    maxc = std::max<int64_t>(maxc, 16 * d);
+    TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, COLSUM_SPLITS * maxc)));
+    h->slab_floats = 32ll << 20;
+    TRY(dev_alloc(h, &h->slab, h->slab_floats));
+    TRY(dev_alloc(h, &h->scalars, 4));
+    return CTX_OK;
+}
+
+SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats}; }
+
+// ---- layer launch helpers -------------------------------------------------------------------------
+NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K}; }
+KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC}; }
+
+// y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
+void conv_layer(ctx_handle* h, const float* x, int nimg, int hb, int wb, int ca, const float* w, const float* b, float* y,
+                int cb) {
+    const int hs = hb / 2, ws = wb / 2, R = nimg * hs * ws;
+    Epi ep;
+    ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
+    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{x, hb, wb, hs, ws, R}, NmC3Weights{w, cb}, ep, R, cb, ws_of(h));
+    else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
+}
+
+// y = act(x W + b), x possibly [x0 | x1] along K
+void fc_layer(ctx_handle* h, const KmPlain& a, int M, int K, const float* w, const float* b, int N, int lrelu, float* y) {
+    Epi ep;
+    ep.out1 = y; ep.ld1 = N; ep.bias = b; ep.lrelu = lrelu;
+    gemm_fc_fwd(h->stream, a, nm(w, N, N, K), ep, M, N, K / KC, ws_of(h));
+}
+
+// dx = dy W^T (+ epilogue): dy [M, N], W [K, N] -> dx [M, K]
+void fc_dx(ctx_handle* h, const float* dy, int M, int N, const float* w, int K, Epi ep) {
+    gemm_fc_dx(h->stream, km(dy, N, M, N), km(w, N, K, N), ep, M, K, N / KC, ws_of(h));
+}
+
+// dW = x^T dy, db = colsum(dy): x [M rows] possibly [x0 | x1] along features
+void fc_dw(ctx_handle* h, const NmPlain& x, int K, const float* dy, int M, int N, float* dw, float* db) {
+    Epi ep;
+    ep.out1 = dw; ep.ld1 = N;
+    gemm_fc_dw(h->stream, x, nm(dy, N, N, M), ep, K, N, (M + KC - 1) / KC, ws_of(h));
+    colsum(h->stream, dy, M, N, h->scratch, db);
+}
+
+struct Scope {
+    float *w[4], *b[4], *w4, *b4, *wz, *bz;
+    float *gw[4], *gb[4], *gw4, *gb4, *gwz, *gbz;
+};
+
+Scope scope_of(ctx_handle* h, const std::string& sc) {
+    Scope s;
+    for (int k = 0; k < 4; ++k) {
+        const std::string base = sc + "/h" + std::to_string(k) + "_conv/";
+        s.w[k] = h->Wp((base + "w").c_str()); s.b[k] = h->Wp((base + "biases").c_str());
+        s.gw[k] = h->Gp((base + "w").c_str()); s.gb[k] = h->Gp((base + "biases").c_str());
+    }
+    s.w4 = h->Wp((sc + "/h4_lin/Matrix").c_str()); s.b4 = h->Wp((sc + "/h4_lin/bias").c_str());
+    s.wz = h->Wp((sc + "/hz_lin/Matrix").c_str()); s.bz = h->Wp((sc + "/hz_lin/bias").c_str());
+    s.gw4 = h->Gp((sc + "/h4_lin/Matrix").c_str()); s.gb4 = h->Gp((sc + "/h4_lin/bias").c_str());
+    s.gwz = h->Gp((sc + "/hz_lin/Matrix").c_str()); s.gbz = h->Gp((sc + "/hz_lin/bias").c_str());
+    return s;
+}
+
+// arm_shaping.py:1282-1288 / :1290-1307: four conv+lrelu, h4_lin+lrelu, hz_lin (+lrelu for `conv`)
+void encoder_fwd(ctx_handle* h, const Scope& sc, const float* x, int nimg, float* const act[5], float* z, int z_lrelu) {
+    const int d = h->d, F = h->F;
+    const float* in = x;
+    int ca = 3;
+    for (int k = 0; k < 4; ++k) {
+        conv_layer(h, in, nimg, h->hh[k], h->ww[k], ca, sc.w[k], sc.b[k], act[k], d << k);
+        in = act[k];
+        ca = d << k;
+    }
+    const int K3 = h->hh[4] * h->ww[4] * 8 * d;   // NHWC flatten, arm_shaping.py:1287
+    fc_layer(h, km(act[3], K3, nimg, K3), nimg, K3, sc.w4, sc.b4, F, 1, act[4]);
+    fc_layer(h, km(act[4], F, nimg, F), nimg, F, sc.wz, sc.bz, F, z_lrelu, z);
+}
+
+enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
+
+// Forward.  TRAIN/EVAL: st = [tgt | src] (2B), decoder = [translated | truth] (2B).
+// TRANSLATE: only what translated_z / out depend on (src encoder, ctx encoder, translate, decoder
+// pass 1) -- the subgraph TF would run for base.py:216-218.  ENCODE: `conv` encoder on src only.
+void forward(ctx_handle* h, int B, Mode mode) {
+    const int d = h->d, F = h->F;
+    const int64_t npi = h->npi;
+    const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
+    float* src_z = h->Z + 2ll * B * F;
+    if (mode == MODE_TRAIN) encoder_fwd(h, st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
+    else encoder_fwd(h, st, h->img + B * npi, B, h->s, src_z, 1);
+    if (mode == MODE_ENCODE) return;
+    encoder_fwd(h, cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+    // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
+    KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC};
+    fc_layer(h, tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
+    fc_layer(h, km(h->th0, F, B, F), B, F, h->Wp("translate/trans_z/Matrix"), h->Wp("translate/trans_z/bias"), F, 0, h->Z);
+    // decoder (arm_shaping.py:1321-1330, :1334-1343)
+    const int nd = mode == MODE_TRAIN ? 2 * B : B;
+    fc_layer(h, km(h->Z, F, nd, F), nd, F, h->Wp("deconv/d_h0_lin/Matrix"), h->Wp("deconv/d_h0_lin/bias"), (int)h->D0, 1, h->dz);
+    const float* dec = h->dz;
+    for (int k = 1; k <= 4; ++k) {
+        const int hs = h->hh[5 - k], ws = h->ww[5 - k];      // input grid of d_hk
+        const int c1 = (16 * d) >> k, c2 = c1;                // decoder stream | ctx skip h_{4-k}
+        const int ca = k < 4 ? (8 * d) >> k : 3;
+        const std::string nm_ = "deconv/d_h" + std::to_string(k);
+        const float* w = h->Wp((nm_ + "/w").c_str());
+        const float* b = h->Wp((nm_ + "/biases").c_str());
+        const float* skip = h->c[4 - k];
+        if (k < 4) {
+            const int R = nd * hs * ws;
+            Epi ep;
+            ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
+            convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R},
+                      KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC}, ep, R, ca, ws_of(h));
+            dec = h->e[k];
+        } else {
+            convt3_fwd(h->stream, ConvT3Args{dec, c1, c1, skip, c2, c2, B, w, b, h->out, nd, hs, ws});
+        }
+    }
+}
+
+// d loss / d params into the grad arena (what AdamOptimizer.minimize differentiates,
+// scripts/train_script.py:128).  Every gradient tensor is written exactly once.
+void backward(ctx_handle* h, int B, int sim_batch) {
+    const int d = h->d, F = h->F;
+    const int64_t npi = h->npi;
+    hipStream_t s = h->stream;
+    const SplitWs ws = ws_of(h);
+    float* tgt_z = h->Z + (int64_t)B * F;
+    float* src_z = h->Z + 2ll * B * F;
+    losses(s, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+
+    // ---- decoder, both passes at once (batch 2B)
+    const float* dy = h->dout;
+    for (int k = 4; k >= 1; --k) {
+        const int hs = h->hh[5 - k], wsm = h->ww[5 - k], hb = 2 * hs, wb = 2 * wsm;
+        const int c1 = (16 * d) >> k, c2 = c1, cb = c1 + c2;
+        const int ca = k < 4 ? (8 * d) >> k : 3;
+        const int R = 2 * B * hs * wsm;
+        const std::string nm_ = "deconv/d_h" + std::to_string(k);
+        const float* w = h->Wp((nm_ + "/w").c_str());
+        const float* dec_in = k > 1 ? h->e[k - 1] : h->dz;      // decoder half of the concat input
+        float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
+        colsum(s, dy, (int64_t)2 * B * hb * wb, ca, h->scratch, h->Gp((nm_ + "/biases").c_str()));
+        NmWgradSmall small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, R};
+        Epi eg;
+        eg.out1 = h->Gp((nm_ + "/w").c_str()); eg.ld1 = cb;
+        // input gradient = SAME stride-2 conv of dy with the same filter read as [5,5,ca,cb]; cols < c1
+        // are the decoder stream (masked by its lrelu), cols >= c1 the ctx skip of this pass
+        Epi ed;
+        ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
+        ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
+        if (ca == 3) {
+            conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, hs, wsm, R}, small, eg, cb, ws);
+            conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R}, NmC3Weights{w, cb}, ed, R, cb, ws);
+        } else {
+            conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws);
+            conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws);
+        }
+        dy = d_dec;
+    }
+    // d_h0_lin: input Z[0:2B] = [trans_z | tgt_z]; simloss adds +-c(trans_z - tgt_z) to its gradient
+    {
+        const int D0 = (int)h->D0;
+        fc_dw(h, nm(h->Z, F, F, 2 * B), F, h->dDz, 2 * B, D0, h->Gp("deconv/d_h0_lin/Matrix"), h->Gp("deconv/d_h0_lin/bias"));
+        Epi ep;
+        ep.out1 = h->dZ; ep.ld1 = F; ep.add1 = h->dsim2; ep.lda1 = F;
+        fc_dx(h, h->dDz, 2 * B, D0, h->Wp("deconv/d_h0_lin/Matrix"), F, ep);
+    }
+    // ---- translate MLP: d trans_z = dZ[0:B]
+    {
+        fc_dw(h, nm(h->th0, F, F, B), F, h->dZ, B, F, h->Gp("translate/trans_z/Matrix"), h->Gp("translate/trans_z/bias"));
+        Epi e1;
+        e1.out1 = h->dth0; e1.ld1 = F; e1.mask = h->th0; e1.ldm = F;
+        fc_dx(h, h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
+        NmPlain tcat{src_z, F, h->cz, F, F, 2 * F, B};
+        fc_dw(h, tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
+        Epi e2;   // d concat: cols < F -> d src_z (row block 2 of dZ), cols >= F -> d ctx_z
+        e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;
+        fc_dx(h, h->dth0, B, F, h->Wp("translate/trans_h0/Matrix"), 2 * F, e2);
+    }
+    // ---- encoders
+    auto encoder_bwd = [&](const Scope& sc, const float* x, int nimg, float* const act[5], float* dzp, float* const dA[5],
+                           bool with_skips) {
+        const int K3 = h->hh[4] * h->ww[4] * 8 * d;
+        fc_dw(h, nm(act[4], F, F, nimg), F, dzp, nimg, F, sc.gwz, sc.gbz);
+        Epi e4;
+        e4.out1 = dA[4]; e4.ld1 = F; e4.mask = act[4]; e4.ldm = F;
+        fc_dx(h, dzp, nimg, F, sc.wz, F, e4);
+        fc_dw(h, nm(act[3], K3, K3, nimg), K3, dA[4], nimg, F, sc.gw4, sc.gb4);
+        Epi e3;
+        e3.out1 = dA[3]; e3.ld1 = K3; e3.mask = act[3]; e3.ldm = K3;
+        if (with_skips) { e3.add1 = h->dSk[3]; e3.lda1 = K3; e3.add2 = h->dSk[3] + (int64_t)B * K3; e3.lda2 = K3; }
+        fc_dx(h, dA[4], nimg, F, sc.w4, K3, e3);
+        for (int k = 3; k >= 0; --k) {
+            const int hb = h->hh[k], wb = h->ww[k], hs = hb / 2, wsm = wb / 2;
+            const int ca = k ? d << (k - 1) : 3, cb = d << k;
+            const int R = nimg * hs * wsm;
+            const float* xin = k ? act[k - 1] : x;
+            colsum(s, dA[k], R, cb, h->scratch, sc.gb[k]);
+            NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, R};
+            Epi eg;
+            eg.out1 = sc.gw[k]; eg.ld1 = cb;
+            if (k == 0) {
+                conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, hs, wsm, R}, small, eg, cb, ws);
+                break;   // no gradient w.r.t. the frame
+            }
+            conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws);
+            // input gradient = conv2d_transpose of dA[k] with the same filter read as [5,5,ca,cb]
+            Epi ed;
+            ed.out1 = dA[k - 1]; ed.ld1 = ca; ed.mask = act[k - 1]; ed.ldm = ca;
+            if (with_skips) {
+                ed.add1 = h->dSk[k - 1]; ed.lda1 = ca;
+                ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
+            }
+            convt_fwd(s, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R}, KmConvTWeights{sc.w[k], ca, cb, cb / KC},
+                      ed, R, ca, ws);
+        }
+    };
+    // `conv` on [tgt | src]: code gradients are rows [B, 3B) of dZ; hz_lin has an lrelu
+    float* dSz = h->dZ + (int64_t)B * F;
+    lrelu_mask(s, dSz, tgt_z, 2ll * B * F);
+    encoder_bwd(scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false);
+    // `conv_context`: linear hz_lin; its h0..h3 also feed both decoder passes as skips
+    encoder_bwd(scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+    h->have_grads = true;
+}
+
+int check_B(ctx_handle* h, int B) {
+    if (!h) return CTX_E_INVALID;
+    if (B <= 0 || B > h->Bm) return fail(h, CTX_E_INVALID, "B=%d outside [1, max_batch=%d]", B, h->Bm);
+    return CTX_OK;
+}
+
+int finish(ctx_handle* h) {
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return CTX_OK;
+}
+
+int adam_step(ctx_handle* h, float lr) {
+    if (!h->have_grads) return fail(h, CTX_E_STATE, "ctx_dev_adam before any backward");
+    const double b1 = 0.9, b2 = 0.999;
+    h->adam_t += 1;
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t));
+    adam(h->stream, h->arena, h->arena + h->Ppad, h->arena + 2 * h->Ppad, h->arena + 3 * h->Ppad, h->Ppad, (float)lr_t,
+         (float)b1, (float)b2, 1e-8f);
+    return CTX_OK;
+}
+
+// host f32 frames -> img slots [tgt | src | ctx]
+int upload_f32(ctx_handle* h, const float* src, const float* ctxf, const float* tgt, int B) {
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, tgt, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, src, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, ctxf, bytes, hipMemcpyHostToDevice, h->stream));
+    return CTX_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int ctx_abi_version(void) { return CTX_ABI_VERSION; }
+
+int64_t ctx_param_total_for(const ctx_config* cfg) {
+    if (check_cfg(cfg, nullptr) != CTX_OK) return CTX_E_INVALID;
+    std::vector<ParamInfo> ps;
+    int64_t total = 0;
+    build_params(*cfg, ps, total);
+    return total;
+}
+
+int64_t ctx_arena_bytes(const ctx_config* cfg) {
+    const int64_t p = ctx_param_total_for(cfg);
+    return p < 0 ? p : 4 * round_up(p, 64) * (int64_t)sizeof(float);
+}
+
+int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, ctx_handle** out) {
+    if (!out) return fail(nullptr, CTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    TRY(check_cfg(cfg, nullptr));
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CTX_E_DEVICE, "no HIP device available (%s); libctxtrans has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, CTX_E_INVALID, "device %d out of range [0,%d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, CTX_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    ctx_handle* h = new ctx_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    h->H = cfg->H; h->W = cfg->W; h->d = cfg->df_dim; h->F = cfg->featsize; h->Bm = cfg->max_batch;
+    for (int k = 0; k < 5; ++k) { h->hh[k] = cfg->H >> k; h->ww[k] = cfg->W >> k; }
+    h->npi = (int64_t)cfg->H * cfg->W * 3;
+    h->D0 = (int64_t)8 * h->d * h->hh[4] * h->ww[4];
+    build_params(*cfg, h->params, h->P);
+    h->Ppad = round_up(h->P, 64);
+    for (auto& p : h->params)
+        if (p.offset % 4) { delete h; return fail(nullptr, CTX_E_INVALID, "parameter %s not 16-byte aligned in the arena", p.name.c_str()); }
+    int rc = CTX_OK;
+    if (stream) h->stream = (hipStream_t)stream;
+    else {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { rc = fail(nullptr, CTX_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    if (rc == CTX_OK) {
+        if (arena) h->arena = (float*)arena;
+        else {
+            rc = dev_alloc(h, &h->arena, 4 * h->Ppad);
+            h->own_arena = true;
+        }
+    }
+    if (rc == CTX_OK) rc = alloc_buffers(h);
+    if (rc == CTX_OK) {
+        e = hipMemsetAsync(h->arena + h->Ppad, 0, 3 * h->Ppad * sizeof(float), h->stream);   // grads, m, v
+        if (e == hipSuccess && h->own_arena) e = hipMemsetAsync(h->arena, 0, h->Ppad * sizeof(float), h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, CTX_E_DEVICE, "arena init: %s", hipGetErrorString(e));
+    }
+    if (rc != CTX_OK) {
+        g_create_error = h->err.empty() ? g_create_error : h->err;
+        ctx_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return CTX_OK;
+}
+
+int ctx_create(const ctx_config* cfg, int device, ctx_handle** out) { return ctx_create_ex(cfg, device, nullptr, nullptr, out); }
+
+void ctx_destroy(ctx_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* ctx_last_error(const ctx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int64_t ctx_param_total(const ctx_handle* h) { return h ? h->P : CTX_E_INVALID; }
+int ctx_param_count(const ctx_handle* h) { return h ? (int)h->params.size() : CTX_E_INVALID; }
+
+int ctx_param_info(const ctx_handle* h, int index, const char** name, int* ndim, int64_t shape[4], int64_t* offset) {
+    if (!h || index < 0 || index >= (int)h->params.size()) return CTX_E_INVALID;
+    const ParamInfo& p = h->params[index];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = p.ndim;
+    if (shape) memcpy(shape, p.shape, sizeof p.shape);
+    if (offset) *offset = p.offset;
+    return CTX_OK;
+}
+
+static int arena_io(ctx_handle* h, int slot, float* host, const float* chost, size_t n) {
+    if (!h) return CTX_E_INVALID;
+    if ((int64_t)n != h->P) return fail(h, CTX_E_INVALID, "expected %lld floats, got %zu", (long long)h->P, n);
+    HIP_TRY(h, hipSetDevice(h->device));
+    float* dev = h->arena + slot * h->Ppad;
+    if (chost) HIP_TRY(h, hipMemcpyAsync(dev, chost, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else HIP_TRY(h, hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+int ctx_set_params(ctx_handle* h, const float* flat, size_t n) { return flat ? arena_io(h, 0, nullptr, flat, n) : CTX_E_INVALID; }
+int ctx_get_params(ctx_handle* h, float* flat, size_t n) { return flat ? arena_io(h, 0, flat, nullptr, n) : CTX_E_INVALID; }
+int ctx_get_grads(ctx_handle* h, float* flat, size_t n) { return flat ? arena_io(h, 1, flat, nullptr, n) : CTX_E_INVALID; }
+
+int ctx_set_adam_state(ctx_handle* h, const float* m, const float* v, size_t n, int64_t step) {
+    if (!h || !m || !v || step < 0) return CTX_E_INVALID;
+    TRY(arena_io(h, 2, nullptr, m, n));
+    TRY(arena_io(h, 3, nullptr, v, n));
+    h->adam_t = step;
+    return CTX_OK;
+}
+
+int ctx_get_adam_state(ctx_handle* h, float* m, float* v, size_t n, int64_t* step) {
+    if (!h) return CTX_E_INVALID;
+    if (m) TRY(arena_io(h, 2, m, nullptr, n));
+    if (v) TRY(arena_io(h, 3, v, nullptr, n));
+    if (step) *step = h->adam_t;
+    return CTX_OK;
+}
+
+int ctx_init_params(ctx_handle* h, uint64_t seed) {
+    if (!h) return CTX_E_INVALID;
+    std::vector<float> host((size_t)h->P, 0.f);
+    std::mt19937_64 rng(seed);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    for (auto& p : h->params) {
+        const bool bias = p.ndim == 1;
+        const bool truncated = p.name.find("_conv/w") != std::string::npos;   // arm_shaping.py:25-26
+        if (bias) continue;
+        for (int64_t i = 0; i < p.size; ++i) {
+            double x = nd(rng);
+            if (truncated) while (std::fabs(x) > 2.0) x = nd(rng);
+            host[(size_t)(p.offset + i)] = (float)(0.02 * x);
+        }
+    }
+    TRY(ctx_set_params(h, host.data(), host.size()));
+    HIP_TRY(h, hipMemsetAsync(h->arena + 2 * h->Ppad, 0, 2 * h->Ppad * sizeof(float), h->stream));
+    h->adam_t = 0;
+    return finish(h);
+}
+
+int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ctx_batched, int B, float* pred, float* feat) {
+    TRY(check_B(h, B));
+    if (!src || !ctx0) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t npi = h->npi;
+    uint8_t* u_src = h->u8;
+    uint8_t* u_ctx = h->u8 + B * npi;
+    HIP_TRY(h, hipMemcpyAsync(u_src, src, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(u_ctx, ctx0, (size_t)(ctx_batched ? B : 1) * npi, hipMemcpyHostToDevice, h->stream));
+    u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
+    if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, B * npi);
+    else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi, B);
+    forward(h, B, MODE_TRANSLATE);
+    if (pred) HIP_TRY(h, hipMemcpyAsync(pred, h->out, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (feat) HIP_TRY(h, hipMemcpyAsync(feat, h->Z, (size_t)B * h->F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
+int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32) {
+    TRY(check_B(h, B));
+    if (!frames) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t npi = h->npi;
+    HIP_TRY(h, hipMemcpyAsync(h->u8, frames, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
+    u8_to_f32(h->stream, h->u8, h->img + B * npi, B * npi);
+    forward(h, B, MODE_ENCODE);
+    if (feat) HIP_TRY(h, hipMemcpyAsync(feat, h->Z + 2ll * B * h->F, (size_t)B * h->F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (frames_f32) HIP_TRY(h, hipMemcpyAsync(frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
+int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B) {
+    TRY(check_B(h, B));
+    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    forward(h, B, MODE_TRAIN);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->F, nullptr, h->F, B, h->scratch, h->scalars);
+    h->last_B = B;
+    HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, int sim_batch) {
+    TRY(check_B(h, B));
+    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    if (sim_batch < 0) return fail(h, CTX_E_INVALID, "sim_batch < 0");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    forward(h, B, MODE_TRAIN);
+    backward(h, B, sim_batch ? sim_batch : B);
+    h->last_B = B;
+    HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_dev_adam(ctx_handle* h, float lr) {
+    if (!h) return CTX_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(adam_step(h, lr));
+    HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_dev_scalars(ctx_handle* h, float scalars[4]) {
+    if (!h || !scalars) return CTX_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+void* ctx_dev_params(ctx_handle* h) { return h ? h->arena : nullptr; }
+void* ctx_dev_grads(ctx_handle* h) { return h ? h->arena + h->Ppad : nullptr; }
+void* ctx_dev_scalar_buf(ctx_handle* h) { return h ? h->scalars : nullptr; }
+void* ctx_stream(ctx_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+int ctx_sync(ctx_handle* h) {
+    if (!h) return CTX_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    return finish(h);
+}
+
+int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const float** input_z, const float** translated_z) {
+    if (!h) return CTX_E_INVALID;
+    if (h->last_B <= 0) return fail(h, CTX_E_STATE, "no training-mode forward has run");
+    const int B = h->last_B;
+    if (out) *out = h->out;
+    if (out2) *out2 = h->out + B * h->npi;
+    if (input_z) *input_z = h->Z + 2ll * B * h->F;
+    if (translated_z) *translated_z = h->Z;
+    return CTX_OK;
+}
+
+int ctx_train_step(ctx_handle* h, const float* src, const float* ctxf, const float* tgt, int B, float lr, float scalars[4]) {
+    TRY(check_B(h, B));
+    if (!src || !ctxf || !tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(upload_f32(h, src, ctxf, tgt, B));
+    forward(h, B, MODE_TRAIN);
+    backward(h, B, B);
+    TRY(adam_step(h, lr));
+    h->last_B = B;
+    if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx8, const uint8_t* tgt, int B, float lr, float scalars[4]) {
+    TRY(check_B(h, B));
+    if (!src || !ctx8 || !tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nb = (size_t)B * h->npi;
+    HIP_TRY(h, hipMemcpyAsync(h->u8, tgt, nb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->u8 + nb, src, nb, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->u8 + 2 * nb, ctx8, nb, hipMemcpyHostToDevice, h->stream));
+    u8_to_f32(h->stream, h->u8, h->img, 3 * (int64_t)nb);
+    forward(h, B, MODE_TRAIN);
+    backward(h, B, B);
+    TRY(adam_step(h, lr));
+    h->last_B = B;
+    if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+int ctx_eval(ctx_handle* h, const float* src, const float* ctxf, const float* tgt, int B, float scalars[4], float* out, float* out2) {
+    TRY(check_B(h, B));
+    if (!src || !ctxf || !tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    TRY(upload_f32(h, src, ctxf, tgt, B));
+    forward(h, B, MODE_TRAIN);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->F, nullptr, h->F, B, h->scratch, h->scalars);
+    h->last_B = B;
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+// Test hook: copy an internal device buffer to the host (names: img Z dZ cz th0 dz out dout dDz dsim2
+// dth0 dcz, s0..s4 c0..c4 dS0..dS4 dC0..dC4 dSk0..dSk3, e1..e3 dE1..dE3).  n = floats to copy.
+int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n) {
+    if (!h || !name || !host) return CTX_E_INVALID;
+    const std::string s(name);
+    const float* p = nullptr;
+    auto idx = [&](const char* pre, int lo, int hi) -> int {
+        const size_t L = strlen(pre);
+        if (s.size() == L + 1 && s.compare(0, L, pre) == 0 && s[L] >= '0' + lo && s[L] <= '0' + hi) return s[L] - '0';
+        return -1;
+    };
+    int k;
+    if (s == "img") p = h->img; else if (s == "Z") p = h->Z; else if (s == "dZ") p = h->dZ;
+    else if (s == "cz") p = h->cz; else if (s == "th0") p = h->th0; else if (s == "dz") p = h->dz;
+    else if (s == "out") p = h->out; else if (s == "dout") p = h->dout; else if (s == "dDz") p = h->dDz;
+    else if (s == "dsim2") p = h->dsim2; else if (s == "dth0") p = h->dth0; else if (s == "dcz") p = h->dcz;
+    else if ((k = idx("dSk", 0, 3)) >= 0) p = h->dSk[k];
+    else if ((k = idx("dS", 0, 4)) >= 0) p = h->dS[k];
+    else if ((k = idx("dC", 0, 4)) >= 0) p = h->dC[k];
+    else if ((k = idx("dE", 1, 3)) >= 0) p = h->dE[k];
+    else if ((k = idx("s", 0, 4)) >= 0) p = h->s[k];
+    else if ((k = idx("c", 0, 4)) >= 0) p = h->c[k];
+    else if ((k = idx("e", 1, 3)) >= 0) p = h->e[k];
+    if (!p) return fail(h, CTX_E_INVALID, "unknown debug buffer '%s'", name);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(host, p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+// conv2d (arm_shaping.py:21-32) and conv2d_transpose (arm_shaping.py:62-85) as implicit GEMMs.
+// The same two kernels also compute each other's input gradient.
+#include "gemm_launch.h"
+namespace ctx {
+void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b, Epi ep, int M, int N, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, 25 * a.cps, ws);
+}
+void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.rowmode = 1; ep.hs = a.hs; ep.ws = a.ws;
+    // no split-K here: the four parity classes have different K extents and M is the pixel count
+    launch_igemm(s, a, b, ep, M, N, 4, 0, ws);
+}
+void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, 3, ws);
+}
+}  // namespace ctx

@@ -1,0 +1,13 @@
+// linear (arm_shaping.py:48-59): forward, input gradient, Matrix gradient
+#include "gemm_launch.h"
+namespace ctx {
+void gemm_fc_fwd(hipStream_t s, const KmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, nchunks, ws);
+}
+void gemm_fc_dx(hipStream_t s, const KmPlain& a, const KmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, nchunks, ws);
+}
+void gemm_fc_dw(hipStream_t s, const NmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, nchunks, ws);
+}
+}  // namespace ctx

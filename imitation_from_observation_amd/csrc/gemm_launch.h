@@ -1,0 +1,43 @@
+// gemm_launch.h -- tile-shape dispatch and split-K policy for igemm_kernel (included by gemm_*.hip)
+#pragma once
+#include "launch.h"
+
+namespace ctx {
+
+void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);
+
+template <class LA, class LB, int MI, int NI>
+static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+    constexpr int TM = 64 * MI, TN = 64 * NI;
+    constexpr size_t lds = (size_t)(Tile<LA::KM, TM>::FLOATS + Tile<LB::KM, TN>::FLOATS) * sizeof(float);
+    dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, nprob * nsplit);
+    hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI>), grid, dim3(NTHREADS), lds, s, a, b, ep, M, N, nprob, nsplit);
+}
+
+// Blocks wanted before the K loop is split: 256 CUs x ~3 resident blocks.
+constexpr int64_t TARGET_BLOCKS = 768;
+
+template <class LA, class LB>
+static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
+                         SplitWs ws) {
+    const int MI = M > 64 ? 2 : 1, NI = N > 64 ? 2 : 1;
+    const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
+    int nsplit = 1;
+    if (tiles < TARGET_BLOCKS / 2 && min_chunks >= 8 && ws.slab) {
+        int64_t want = (TARGET_BLOCKS + tiles - 1) / tiles;
+        int64_t cap_k = min_chunks / 4;                                   // >= 4 chunks per split
+        int64_t cap_ws = ws.slab_floats / ((int64_t)nprob * M * N);
+        int64_t n = want < cap_k ? want : cap_k;
+        if (n > cap_ws) n = cap_ws;
+        if (n > 64) n = 64;
+        if (n > 1) nsplit = (int)n;
+    }
+    ep.slab = nsplit > 1 ? ws.slab : nullptr;
+    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else if (MI == 2) launch_tile<LA, LB, 2, 1>(s, a, b, ep, M, N, nprob, nsplit);
+    else if (NI == 2) launch_tile<LA, LB, 1, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else launch_tile<LA, LB, 1, 1>(s, a, b, ep, M, N, nprob, nsplit);
+    if (nsplit > 1) splitk_reduce(s, ep, M, N, nprob, nsplit);
+}
+
+}  // namespace ctx

@@ -1,0 +1,12 @@
+// filter gradients of conv2d / conv2d_transpose: 25 taps = 25 problems, reduction over pixels
+#include "gemm_launch.h"
+namespace ctx {
+void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.prob_stride = (int64_t)M * N;
+    launch_igemm(s, a, b, ep, M, N, 25, (a.npix + KC - 1) / KC, ws);
+}
+void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
+    ep.rowmode = 2;
+    launch_igemm(s, a, b, ep, 80, N, 1, (a.npix + KC - 1) / KC, ws);
+}
+}  // namespace ctx

@@ -1,0 +1,66 @@
+// launch.h -- host-callable launchers of every HIP kernel in libctxtrans (all enqueue on `s`, none
+// synchronise).  Definitions: gemm_*.hip (implicit-GEMM instantiations) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm.h"
+
+namespace ctx {
+
+// Split-K policy shared by all launchers: `slab` is scratch of `slab_floats` floats.
+struct SplitWs {
+    float* slab;
+    int64_t slab_floats;
+};
+
+// Each launcher computes D = A*B through igemm_kernel with the given loader pair; nprob problems
+// share M, N (transposed-conv parity classes, filter-gradient taps).  min_chunks = smallest K-chunk
+// count over the problems (bounds the split).
+void gemm_fc_fwd(hipStream_t s, const KmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
+void gemm_fc_dx(hipStream_t s, const KmPlain& a, const KmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
+void gemm_fc_dw(hipStream_t s, const NmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
+void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b, Epi ep, int M, int N, SplitWs ws);
+void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws);
+void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws);
+void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
+void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
+
+// conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330): direct VALU kernel.
+struct ConvT3Args {
+    const float* s1; int64_t ld1; int c1;   // decoder stream [nimg, hs, ws, c1]
+    const float* s2; int64_t ld2; int c2;   // ctx skip [nmod2, hs, ws, c2]
+    int nmod2;
+    const float* w;                         // [5][5][3][c1+c2]
+    const float* bias;                      // [3]
+    float* out;                             // [nimg, 2hs, 2ws, 3]
+    int nimg, hs, ws;
+};
+void convt3_fwd(hipStream_t s, const ConvT3Args& a);
+
+// (x * 1/255 - 0.5) * 2 in unfused f32 ops (rllab/sampler/base.py:116-119)
+void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
+// out[r] = in[r % nrows_in] -- the [context]*batch_size broadcast of base.py:217-218
+void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows);
+
+// Losses (arm_shaping.py:1345,1352-1354) and their seeds of the backward pass.
+//   out [2B, npi] (rows < B: translated pass, rows >= B: truth pass), tgt [B, npi]
+//   dout (nullable) = out - tgt[n % B]
+//   tz, tgt_z [B, F]; dsim2 (nullable) [2B, F] = [+c (tz - tgt_z); -c (tz - tgt_z)], c = 2e3/(sim_batch F)
+//   scalars[4] = {loss, simloss, recon1, recon2};  scratch: >= 4 * LOSS_BLOCKS floats
+constexpr int LOSS_BLOCKS = 512;
+void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
+            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars);
+
+// db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * C floats
+constexpr int COLSUM_SPLITS = 128;
+void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out);
+
+// g *= (act >= 0 ? 1 : 0.2)
+void lrelu_mask(hipStream_t s, float* g, const float* act, int64_t n);
+
+// TF Adam (scripts/train_script.py:124-128): lr_t precomputed on the host
+void adam(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2,
+          float eps);
+
+}  // namespace ctx

@@ -1,0 +1,274 @@
+"""Python host of the translator: a thin ctypes layer over libctxtrans.so.
+
+`Translator.translate(obs_src, obs_tgt0) -> (pred_frame, feat)` is the call the reference's reward
+hook makes as `sess.run([model.translated_z, model.out], {image: [src, [ctx]*B, [ctx]*B]})`
+(rllab/sampler/base.py:216-218); `encode` is `sess.run([model.input_z, image_trans], ...)`
+(base.py:234-235); `train_step` / `evaluate` are scripts/train_script.py:163 / :176.  All arithmetic
+happens in the HIP kernels; this file only moves numpy buffers across the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import CtxConfig, CtxError  # noqa: F401
+
+_FP = ctypes.POINTER(ctypes.c_float)
+_UP = ctypes.POINTER(ctypes.c_uint8)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _u8(a, shape=None):
+    a = np.asarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError(f"expected uint8 frames, got {a.dtype}")
+    a = np.ascontiguousarray(a)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(_FP)
+
+
+def _up(a):
+    return a.ctypes.data_as(_UP)
+
+
+class Translator:
+    """One ContextSkipNew model (gym/envs/mujoco/arm_shaping.py:1260-1354) resident on one MI355X.
+
+    Thread-compatible, not thread-safe -- like the single tf.Session it replaces.
+    """
+
+    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None):
+        self._lib = _lib.load()
+        self.cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, max_batch, 0)
+        self.H, self.W, self.df_dim, self.featsize, self.max_batch = H, W, df_dim, featsize, max_batch
+        self.device = device
+        self._h = ctypes.c_void_p()
+        rc = self._lib.ctx_create_ex(ctypes.byref(self.cfg), device, ctypes.c_void_p(stream or 0),
+                                     ctypes.c_void_p(arena_ptr or 0), ctypes.byref(self._h))
+        if rc != _lib.CTX_OK:
+            msg = self._lib.ctx_last_error(None)
+            self._h = ctypes.c_void_p()
+            raise CtxError(rc, msg.decode() if msg else "")
+        self.n_params = int(self._lib.ctx_param_total(self._h))
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        _lib.check(self._lib, self._h, rc)
+
+    @staticmethod
+    def param_total(H=64, W=64, df_dim=64, featsize=1024):
+        cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, 1, 0)
+        return int(_lib.load().ctx_param_total_for(ctypes.byref(cfg)))
+
+    @staticmethod
+    def arena_floats(H=64, W=64, df_dim=64, featsize=1024):
+        cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, 1, 0)
+        return int(_lib.load().ctx_arena_bytes(ctypes.byref(cfg))) // 4
+
+    # ------------------------------------------------------------------ parameters (tf.train.Saver)
+    def param_info(self):
+        """[(tf_variable_name, shape, offset)] in arena order."""
+        out = []
+        for i in range(self._lib.ctx_param_count(self._h)):
+            name, ndim, off = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_int64()
+            shape = (ctypes.c_int64 * 4)()
+            self._ck(self._lib.ctx_param_info(self._h, i, ctypes.byref(name), ctypes.byref(ndim), shape, ctypes.byref(off)))
+            out.append((name.value.decode(), tuple(int(shape[k]) for k in range(ndim.value)), int(off.value)))
+        return out
+
+    def init_params(self, seed=0):
+        self._ck(self._lib.ctx_init_params(self._h, ctypes.c_uint64(seed)))
+
+    def set_params_flat(self, flat):
+        flat = _f32(flat, (self.n_params,))
+        self._ck(self._lib.ctx_set_params(self._h, _fp(flat), flat.size))
+
+    def get_params_flat(self):
+        flat = np.empty(self.n_params, np.float32)
+        self._ck(self._lib.ctx_get_params(self._h, _fp(flat), flat.size))
+        return flat
+
+    def get_grads_flat(self):
+        flat = np.empty(self.n_params, np.float32)
+        self._ck(self._lib.ctx_get_grads(self._h, _fp(flat), flat.size))
+        return flat
+
+    def _split(self, flat):
+        return OrderedDict((n, flat[o:o + int(np.prod(s))].reshape(s)) for n, s, o in self.param_info())
+
+    def set_params(self, tree, prefix=""):
+        """tree: {tf_variable_name: array}; `prefix` strips e.g. 'contextmodel/' (train_script.py:120)."""
+        flat = np.empty(self.n_params, np.float32)
+        for n, s, o in self.param_info():
+            a = np.asarray(tree[prefix + n], np.float32)
+            if tuple(a.shape) != s:
+                raise ValueError(f"{n}: expected {s}, got {a.shape}")
+            flat[o:o + a.size] = a.reshape(-1)
+        self.set_params_flat(flat)
+
+    def get_params(self):
+        return self._split(self.get_params_flat())
+
+    def get_grads(self):
+        return self._split(self.get_grads_flat())
+
+    def get_adam_state(self):
+        m = np.empty(self.n_params, np.float32)
+        v = np.empty(self.n_params, np.float32)
+        step = ctypes.c_int64()
+        self._ck(self._lib.ctx_get_adam_state(self._h, _fp(m), _fp(v), m.size, ctypes.byref(step)))
+        return m, v, int(step.value)
+
+    def set_adam_state(self, m, v, step):
+        m, v = _f32(m, (self.n_params,)), _f32(v, (self.n_params,))
+        self._ck(self._lib.ctx_set_adam_state(self._h, _fp(m), _fp(v), m.size, int(step)))
+
+    def save(self, path, with_adam=True, prefix=""):
+        """Checkpoint keyed by the TF variable names (the Saver's, train_script.py:181)."""
+        tree = {prefix + k: v for k, v in self.get_params().items()}
+        if with_adam:
+            m, v, step = self.get_adam_state()
+            tree["__adam_m__"], tree["__adam_v__"], tree["__adam_step__"] = m, v, np.int64(step)
+        np.savez(path, **tree)
+
+    def load(self, path, prefix=""):
+        """saver.restore (base.py:144-145): accepts names with or without the 'contextmodel/' scope."""
+        with np.load(path) as z:
+            keys = set(z.files)
+            first = self.param_info()[0][0]
+            if prefix + first not in keys and "contextmodel/" + first in keys:
+                prefix = "contextmodel/"
+            self.set_params({k: z[k] for k in keys if not k.startswith("__")}, prefix=prefix)
+            if "__adam_m__" in keys:
+                self.set_adam_state(z["__adam_m__"], z["__adam_v__"], int(z["__adam_step__"]))
+
+    # ------------------------------------------------------------------ inference (reward hook)
+    def translate(self, obs_src, obs_tgt0):
+        """obs_src uint8 [B,H,W,3]; obs_tgt0 uint8 [H,W,3] (first frame of the target context,
+        broadcast like `[context] * batch_size`) or [B,H,W,3].  Returns (pred_frame f32 [B,H,W,3],
+        feat f32 [B,featsize]) = (model.out, model.translated_z)."""
+        src = _u8(obs_src)
+        if src.ndim != 4 or src.shape[1:] != (self.H, self.W, 3):
+            raise ValueError(f"obs_src must be [B,{self.H},{self.W},3], got {src.shape}")
+        B = src.shape[0]
+        ctx0 = _u8(obs_tgt0)
+        batched = ctx0.ndim == 4
+        if tuple(ctx0.shape) != ((B, self.H, self.W, 3) if batched else (self.H, self.W, 3)):
+            raise ValueError(f"obs_tgt0 has shape {ctx0.shape}")
+        pred = np.empty((B, self.H, self.W, 3), np.float32)
+        feat = np.empty((B, self.featsize), np.float32)
+        self._ck(self._lib.ctx_translate(self._h, _up(src), _up(ctx0), int(batched), B, _fp(pred), _fp(feat)))
+        return pred, feat
+
+    def encode(self, frames, return_frames=True):
+        """frames uint8 [B,H,W,3] -> (input_z f32 [B,featsize], image_trans[0] f32 [B,H,W,3])."""
+        fr = _u8(frames)
+        if fr.ndim != 4 or fr.shape[1:] != (self.H, self.W, 3):
+            raise ValueError(f"frames must be [B,{self.H},{self.W},3], got {fr.shape}")
+        B = fr.shape[0]
+        feat = np.empty((B, self.featsize), np.float32)
+        f32 = np.empty(fr.shape, np.float32) if return_frames else None
+        self._ck(self._lib.ctx_encode(self._h, _up(fr), B, _fp(feat), _fp(f32) if return_frames else None))
+        return feat, f32
+
+    # ------------------------------------------------------------------ training
+    def _triple(self, src, ctx, tgt):
+        src = _f32(src)
+        shp = (src.shape[0], self.H, self.W, 3)
+        return _f32(src, shp), _f32(ctx, shp), _f32(tgt, shp), shp[0]
+
+    def train_step(self, src, ctx, tgt, lr=1e-4):
+        """One Adam step on f32 frames in [-1,1]; returns dict(loss, simloss, recon1, recon2)."""
+        src, ctx, tgt, B = self._triple(src, ctx, tgt)
+        sc = np.empty(4, np.float32)
+        self._ck(self._lib.ctx_train_step(self._h, _fp(src), _fp(ctx), _fp(tgt), B, float(lr), _fp(sc)))
+        return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
+    def train_step_u8(self, src, ctx, tgt, lr=1e-4):
+        src = _u8(src)
+        shp = (src.shape[0], self.H, self.W, 3)
+        src, ctx, tgt = _u8(src, shp), _u8(ctx, shp), _u8(tgt, shp)
+        sc = np.empty(4, np.float32)
+        self._ck(self._lib.ctx_train_step_u8(self._h, _up(src), _up(ctx), _up(tgt), shp[0], float(lr), _fp(sc)))
+        return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
+    def evaluate(self, src, ctx, tgt, outputs=True):
+        """Forward + losses (train_script.py:176,192-193)."""
+        src, ctx, tgt, B = self._triple(src, ctx, tgt)
+        sc = np.empty(4, np.float32)
+        out = np.empty(src.shape, np.float32) if outputs else None
+        out2 = np.empty(src.shape, np.float32) if outputs else None
+        self._ck(self._lib.ctx_eval(self._h, _fp(src), _fp(ctx), _fp(tgt), B, _fp(sc),
+                                    _fp(out) if outputs else None, _fp(out2) if outputs else None))
+        res = dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+        if outputs:
+            res["out"], res["out2"] = out, out2
+        return res
+
+    # ------------------------------------------------------------------ device-resident phases
+    def dev_forward_backward(self, d_src, d_ctx, d_tgt, B, sim_batch=0):
+        """d_*: integer device addresses of f32 [B,H,W,3].  Asynchronous on the handle's stream."""
+        self._ck(self._lib.ctx_dev_forward_backward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx),
+                                                     ctypes.c_void_p(d_tgt), B, sim_batch))
+
+    def dev_forward(self, d_src, d_ctx, d_tgt, B):
+        self._ck(self._lib.ctx_dev_forward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt), B))
+
+    def dev_adam(self, lr=1e-4):
+        self._ck(self._lib.ctx_dev_adam(self._h, float(lr)))
+
+    def dev_scalars(self):
+        sc = np.empty(4, np.float32)
+        self._ck(self._lib.ctx_dev_scalars(self._h, _fp(sc)))
+        return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
+    def sync(self):
+        self._ck(self._lib.ctx_sync(self._h))
+
+    @property
+    def stream_ptr(self):
+        return self._lib.ctx_stream(self._h) or 0
+
+    @property
+    def grads_ptr(self):
+        return self._lib.ctx_dev_grads(self._h)
+
+    @property
+    def scalars_ptr(self):
+        return self._lib.ctx_dev_scalar_buf(self._h)
+
+    def debug_read(self, name, n):
+        out = np.empty(int(n), np.float32)
+        self._ck(self._lib.ctx_debug_read(self._h, name.encode(), _fp(out), out.size))
+        return out

@@ -1,0 +1,153 @@
+/*
+ * ctxtrans.h -- C ABI of libctxtrans.so: the context-translation encoder/decoder
+ * ("translator") of imitation_from_observation as hand-written HIP kernels for gfx950.
+ *
+ * The reference has no FFI for this path; its boundary is the TensorFlow feed/fetch contract used
+ * at four call sites plus Saver.restore/save.  Every entry point below replaces one of them
+ * (paths relative to the reference root):
+ *
+ *   ctx_create            Model().build(placeholder)            rllab/sampler/base.py:134-138,
+ *                                                               scripts/train_script.py:118-121
+ *   ctx_param_* / set / get   tf.train.Saver var list, restore/save   base.py:144-145,
+ *                                                               train_script.py:133,181
+ *   ctx_init_params       tf.global_variables_initializer       train_script.py:129
+ *   ctx_translate         sess.run([translated_z, out], {image:[src,[ctx]*B,[ctx]*B]})
+ *                                                               base.py:216-218
+ *   ctx_encode            sess.run([input_z, image_trans], ...) base.py:234-235
+ *   ctx_train_step        sess.run([optimizer, loss, simloss, recon1, recon2], ...)
+ *                                                               train_script.py:163,167
+ *   ctx_eval              sess.run([loss, simloss, recon1, recon2, out, out2], ...)
+ *                                                               train_script.py:176,192-193
+ *   ctx_dev_*             the same train step split into device-resident phases so a host can put
+ *                         an RCCL gradient all-reduce between backward and Adam (new: the
+ *                         reference has no multi-GPU path)
+ *
+ * Conventions: every function returns 0 on success or a negative CTX_E_* code; the message is
+ * available from ctx_last_error().  No C++ exception crosses the ABI.  Host buffers are caller
+ * owned and only touched during the call.  Layouts are the reference's: frames NHWC uint8 / f32,
+ * parameters flat f32 in ctx_param_info order (TF variable names and shapes).  A handle is bound
+ * to one device and is thread-compatible, not thread-safe (one caller at a time, like the single
+ * tf.Session user).  There is NO CPU fallback: without a usable gfx950 device ctx_create fails.
+ */
+#ifndef CTXTRANS_H
+#define CTXTRANS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTX_ABI_VERSION 1
+
+enum {
+    CTX_OK = 0,
+    CTX_E_INVALID = -1,   /* bad argument / unsupported configuration */
+    CTX_E_DEVICE = -2,    /* HIP runtime error (no device, launch failure, ...) */
+    CTX_E_NOMEM = -3,     /* device allocation failed */
+    CTX_E_STATE = -4      /* call sequence error (e.g. adam before backward) */
+};
+
+enum {
+    CTX_VARIANT_SKIPNEW = 0 /* ContextSkipNew, gym/envs/mujoco/arm_shaping.py:1260-1354 */
+};
+
+typedef struct ctx_config {
+    int32_t variant;    /* CTX_VARIANT_* */
+    int32_t H, W, C;    /* frame size; H, W multiples of 16 (arm_shaping.py:1314-1319); C == 3 */
+    int32_t df_dim;     /* encoder/decoder base width (df_dim == gf_dim == 64 in the reference);
+                           multiple of 32 */
+    int32_t featsize;   /* 1024 in the reference (arm_shaping.py:1277); multiple of 32 */
+    int32_t max_batch;  /* largest B any later call will pass */
+    int32_t reserved;
+} ctx_config;
+
+typedef struct ctx_handle ctx_handle;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+int ctx_abi_version(void);
+/* Allocates everything on `device` with hipMalloc and creates a private stream. */
+int ctx_create(const ctx_config* cfg, int device, ctx_handle** out);
+/* Same, on caller-owned resources: `stream` is a hipStream_t (NULL = private stream), `arena` is
+ * device memory of ctx_arena_bytes(cfg) bytes laid out [params | grads | adam_m | adam_v], each
+ * ctx_param_total floats (NULL = allocate).  Lets a host framework own the gradient buffer it
+ * hands to its collective library. */
+int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, ctx_handle** out);
+void ctx_destroy(ctx_handle* h);
+/* Message of the last failed call on `h` (or of the last failed ctx_create when h == NULL). */
+const char* ctx_last_error(const ctx_handle* h);
+
+/* ---- parameter inventory (TF variable names) ------------------------------------------------ */
+int64_t ctx_param_total_for(const ctx_config* cfg); /* number of f32 parameters, <0 on error */
+int64_t ctx_arena_bytes(const ctx_config* cfg);     /* 4 * 4 * ctx_param_total_for */
+int64_t ctx_param_total(const ctx_handle* h);
+int ctx_param_count(const ctx_handle* h);           /* number of tensors */
+/* name: e.g. "conv/h0_conv/w"; shape: up to 4 dims, unused = 1; offset: in floats into the arena */
+int ctx_param_info(const ctx_handle* h, int index, const char** name, int* ndim, int64_t shape[4],
+                   int64_t* offset);
+int ctx_set_params(ctx_handle* h, const float* flat, size_t n);
+int ctx_get_params(ctx_handle* h, float* flat, size_t n);
+int ctx_get_grads(ctx_handle* h, float* flat, size_t n); /* gradient of the last backward */
+/* Adam slots + step counter (Saver saves them too, train_script.py:133). */
+int ctx_set_adam_state(ctx_handle* h, const float* m, const float* v, size_t n, int64_t step);
+int ctx_get_adam_state(ctx_handle* h, float* m, float* v, size_t n, int64_t* step);
+/* conv w: truncated normal(0.02); deconv w, FC Matrix: normal(0.02); biases 0
+ * (arm_shaping.py:25-29, 52-55, 67-68, 79).  Also zeroes the Adam state. */
+int ctx_init_params(ctx_handle* h, uint64_t seed);
+
+/* ---- inference: the rllab reward hook's two fetches ------------------------------------------ */
+/* translate(obs_src, obs_tgt0) -> (pred_frame, feat).
+ * src  [B,H,W,3] uint8; ctx0 [H,W,3] uint8 (ctx_batched == 0, broadcast to B like base.py's
+ * [context]*batch_size) or [B,H,W,3] (ctx_batched != 0).
+ * pred [B,H,W,3] f32 = model.out; feat [B,featsize] f32 = model.translated_z.  Either may be NULL. */
+int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ctx_batched, int B,
+                  float* pred, float* feat);
+/* frames [B,H,W,3] uint8 -> feat [B,featsize] = model.input_z; frames_f32 (nullable) [B,H,W,3] =
+ * image_trans[0] = (x/255 - 0.5)*2. */
+int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32);
+
+/* ---- training --------------------------------------------------------------------------------- */
+/* src/ctx/tgt [B,H,W,3] f32 in [-1,1] (tfinput[0], [1], [2]).  scalars = {loss, simloss, recon1,
+ * recon2} of the forward pass before the update.  Adam: TF defaults b1 .9, b2 .999, eps 1e-8. */
+int ctx_train_step(ctx_handle* h, const float* src, const float* ctx, const float* tgt, int B,
+                   float lr, float scalars[4]);
+/* Same on uint8 frames, preprocessed on device with (x/255 - 0.5)*2. */
+int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx, const uint8_t* tgt,
+                      int B, float lr, float scalars[4]);
+/* Forward + losses only.  out / out2 (nullable) [B,H,W,3]. */
+int ctx_eval(ctx_handle* h, const float* src, const float* ctx, const float* tgt, int B,
+             float scalars[4], float* out, float* out2);
+
+/* ---- device-resident phases (benchmarks, data parallel) -------------------------------------- */
+/* d_* are DEVICE pointers [B,H,W,3] f32.  Enqueues forward + backward on the handle's stream and
+ * returns without synchronising.  sim_batch: batch in the simloss mean's denominator (0 = B); a
+ * data-parallel shard passes the GLOBAL batch so a SUM all-reduce of the gradient arena equals the
+ * full-batch gradient. */
+int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_ctx,
+                             const float* d_tgt, int B, int sim_batch);
+int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt,
+                    int B);
+/* Fused multi-tensor Adam over the whole arena with the gradients currently in the grad arena. */
+int ctx_dev_adam(ctx_handle* h, float lr);
+/* Synchronises and copies {loss, simloss, recon1, recon2} of the last forward. */
+int ctx_dev_scalars(ctx_handle* h, float scalars[4]);
+void* ctx_dev_params(ctx_handle* h); /* device pointers into the arena */
+void* ctx_dev_grads(ctx_handle* h);
+void* ctx_dev_scalar_buf(ctx_handle* h); /* device f32[4] written by the last forward */
+void* ctx_stream(ctx_handle* h);         /* hipStream_t the kernels are enqueued on */
+int ctx_sync(ctx_handle* h);
+/* Device outputs of the last forward (valid until the next call): model.out / out2 [B,H,W,3],
+ * input_z / translated_z [B,featsize]. */
+int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const float** input_z,
+                    const float** translated_z);
+
+/* ---- test hook ------------------------------------------------------------------------------- */
+/* Copies n floats of a named internal activation / gradient buffer to the host (bring-up and
+ * parity tests only; names are listed in csrc/ctxtrans.cpp). */
+int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTXTRANS_H */

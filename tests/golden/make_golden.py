@@ -1,0 +1,97 @@
+"""Generates the committed golden vectors under tests/golden/ from the float64 oracle.
+
+The reference itself cannot run in the build container (TensorFlow absent), so these
+are outputs of oracle/ctx_oracle.py -- which tests/test_oracle.py pins against an independent
+torch-autograd statement -- NOT outputs of the reference.  Run:  python tests/golden/make_golden.py
+
+Fixtures hold data only: seeds, uint8 input frames, outputs, gradient / parameter digests.
+Parameters are regenerated in the tests from the recorded seed (a digest guards RNG drift).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ctx_oracle as o  # noqa: E402
+
+N_HEAD = 64
+
+
+def digest(a):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())]), a[:N_HEAD].copy()
+
+
+def synth_frames(seed, B, H, W):
+    """SURVEY.md 8d synthetic inputs: iid uint8 frames, one seed per slot."""
+    return np.random.default_rng(seed).integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+
+
+def blob_frames(seed, B, H, W):
+    """Low-frequency 'rendered-looking' frames: sum of 4 random 2-D Gaussians per channel."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    out = np.zeros((B, H, W, 3))
+    for b in range(B):
+        for c in range(3):
+            for _ in range(4):
+                cy, cx, s, a = rng.uniform(0, H), rng.uniform(0, W), rng.uniform(H / 8, H / 2), rng.uniform(0.2, 1)
+                out[b, :, :, c] += a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+    out = out / out.max()
+    return np.clip(np.round(out * 255), 0, 255).astype(np.uint8)
+
+
+def make(tag, cfg, B, pseed, stddev, frames, steps, lr=1e-4):
+    p = o.init_params(cfg, pseed, np.float64, stddev=stddev)
+    # non-zero biases so every bias path is exercised
+    brng = np.random.default_rng(pseed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    su8, cu8, tu8 = (frames(s, B, cfg.H, cfg.W) for s in (0, 1, 2))
+    src, ctx, tgt = (o.preprocess_u8(x).astype(np.float64) for x in (su8, cu8, tu8))
+    fx = dict(cfg=np.array([cfg.H, cfg.W, cfg.C, cfg.df_dim, cfg.featsize]), B=B, pseed=pseed, stddev=stddev,
+              src_u8=su8, ctx_u8=cu8, tgt_u8=tu8, lr=lr, steps=steps)
+    fx["param_digest"], _ = digest(o.flatten(p, cfg))
+    res, c = o.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        fx[k] = res[k].astype(np.float32)
+    fx["scalars"] = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]])
+    g = o.backward(p, c, cfg)
+    names = [n for n, _ in o.param_specs(cfg)]
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_head"] = np.stack([np.pad(digest(g[n])[1], (0, N_HEAD - min(N_HEAD, g[n].size))) for n in names])
+    # inference call sites on the same frames
+    pred, feat = o.translate({k: v.astype(np.float32) for k, v in p.items()}, su8, cu8[0], cfg)
+    fx["translate_pred"], fx["translate_feat"] = pred.astype(np.float32), feat.astype(np.float32)
+    ef, _ = o.encode({k: v.astype(np.float32) for k, v in p.items()}, su8, cfg)
+    fx["encode_feat"] = ef.astype(np.float32)
+    # Adam trajectory
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    traj = []
+    p0 = o.flatten(p, cfg)
+    for t in range(1, steps + 1):
+        r, _ = o.train_step(p, m, v, t, src, ctx, tgt, lr, cfg)
+        traj.append([r["loss"], r["simloss"], r["recon1"], r["recon2"]])
+    fx["train_scalars"] = np.array(traj)
+    delta = o.flatten(p, cfg) - p0
+    fx["delta_digest"] = np.stack([digest(dd)[0] for dd in np.split(delta, np.cumsum(
+        [int(np.prod(s)) for _, s in o.param_specs(cfg)])[:-1])])
+    fx["delta_head"] = delta[:N_HEAD]
+    path = os.path.join(HERE, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
+
+
+if __name__ == "__main__":
+    # reduced net the HIP kernels accept (channels multiples of 32), iid frames
+    make("skipnew_d32_f128_32x32_b4", o.SkipNewConfig(H=32, W=32, df_dim=32, gf_dim=32, featsize=128), 4, 1234, 0.05,
+         synth_frames, steps=3)
+    # non-square, blob frames
+    make("skipnew_d32_f128_16x48_b3", o.SkipNewConfig(H=16, W=48, df_dim=32, gf_dim=32, featsize=128), 3, 77, 0.05,
+         blob_frames, steps=2)
+    # the production net at the reference's init scale
+    make("skipnew_d64_f1024_64x64_b2", o.SkipNewConfig(), 2, 1234, 0.02, synth_frames, steps=2)

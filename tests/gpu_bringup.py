@@ -1,0 +1,72 @@
+"""GPU bring-up report (not collected by pytest): runs one training-mode forward/backward of the HIP
+path and prints, per internal buffer and per parameter gradient, the error against the oracle.
+Usage on the GPU box:  python tests/gpu_bringup.py [H W df F B]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imitation_from_observation_amd import Translator  # noqa: E402
+from oracle import ctx_oracle as o  # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def main(H=32, W=32, d=32, F=128, B=4, stddev=0.05):
+    cfg = o.SkipNewConfig(H=H, W=W, df_dim=d, gf_dim=d, featsize=F)
+    p = o.init_params(cfg, 1234, np.float64, stddev=stddev)
+    brng = np.random.default_rng(1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    rng = np.random.default_rng(0)
+    src, ctx, tgt = (rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32) for _ in range(3))
+    t0 = time.time()
+    res, c = o.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = o.backward(p, c, cfg)
+    print(f"oracle fwd+bwd {time.time() - t0:.2f}s  loss {res['loss']:.6f}")
+    tr = Translator(H, W, d, F, max_batch=B)
+    tr.set_params({k: v.astype(np.float32) for k, v in p.items()})
+    r = tr.evaluate(src, ctx, tgt)
+    print("eval scalars hip   ", [r[k] for k in ("loss", "simloss", "recon1", "recon2")])
+    print("eval scalars oracle", [float(res[k]) for k in ("loss", "simloss", "recon1", "recon2")])
+    cat = np.concatenate
+    ref = {"img": cat([tgt, src, ctx])}
+    for k in range(5):
+        ref[f"s{k}"] = cat([c["e_tgt"][k], c["e_src"][k]])
+        ref[f"c{k}"] = c["e_ctx"][k]
+    ref["Z"] = cat([c["trans_z"], c["e_tgt"][5], c["e_src"][5]])
+    ref["cz"] = c["e_ctx"][5]
+    ref["th0"] = c["trans_h0"]
+    ref["dz"] = cat([c["d1"][0], c["d2"][0]])
+    for k in range(1, 4):
+        ref[f"e{k}"] = cat([c["d1"][k], c["d2"][k]])
+    ref["out"] = cat([c["d1"][4], c["d2"][4]])
+    bad = 0
+    for name in ["img", "s0", "s1", "s2", "s3", "s4", "c0", "c1", "c2", "c3", "c4", "cz", "Z", "th0", "dz", "e1", "e2", "e3", "out"]:
+        got = tr.debug_read(name, ref[name].size)
+        e = rel(got, ref[name])
+        bad += e > 1e-4
+        print(f"  fwd {name:4s} {str(ref[name].shape):22s} rel_err {e:.3e} {'' if e <= 1e-4 else '<<<<<<'}")
+    # backward through the phase API on a plain hipMalloc'd copy of the inputs via train_step with lr=0
+    sc = tr.train_step(src, ctx, tgt, lr=0.0)
+    print("train scalars hip  ", sc)
+    gg = tr.get_grads()
+    order = [n for n, _ in o.param_specs(cfg)]
+    for n in reversed(order):
+        e = rel(gg[n], g[n])
+        bad += e > 1e-3
+        print(f"  grad {n:32s} {str(g[n].shape):20s} rel_err {e:.3e} |g|max {np.abs(g[n]).max():.3e} {'' if e <= 1e-3 else '<<<<<<'}")
+    print("BRINGUP", "OK" if bad == 0 else f"FAILED ({bad} mismatches)")
+    tr.close()
+    return bad
+
+
+if __name__ == "__main__":
+    args = [int(a) for a in sys.argv[1:]]
+    sys.exit(1 if main(*args) else 0)
