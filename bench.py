@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""bench.py -- translator training throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = forward + backward + Adam of ContextSkipNew at 64x64x3 on a per-GPU batch of 256
+synthetic (src, ctx, tgt) frame triples that are already resident in HBM (BASELINE.json
+configs[1]; weak scaling: every rank has its own 256).  With N > 1 the gradient arena is
+sum-all-reduced over RCCL between backward and Adam (the path has one exchange step).
+Prints ONE JSON line on rank 0.  PyTorch is plumbing only: device buffers, the stream, RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = W = 64
+DF, FEAT = 64, 1024
+FLOPS_FWD_BWD_PER_TRIPLE = 7_072_382_976
+BYTES_PER_TRIPLE = 15_155_200
+BYTES_PER_STEP_FIXED = 1_905_912_440
+PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM = 8.0e12
+
+
+def cpu_baseline(batch, steps):
+    """The numpy oracle (a port of the reference's arithmetic; the reference's TensorFlow path cannot
+    run here) timed on the host cores on a bounded sample: `steps` train steps at batch `batch`."""
+    from oracle import ctx_oracle as o
+    cfg = o.SkipNewConfig(H=H, W=W, df_dim=DF, gf_dim=DF, featsize=FEAT)
+    p = o.init_params(cfg, 0, np.float32)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    rng = np.random.default_rng(0)
+    src, ctx, tgt = (rng.uniform(-1, 1, (batch, H, W, 3)).astype(np.float32) for _ in range(3))
+    o.train_step(p, m, v, 1, src, ctx, tgt, 1e-4, cfg)          # warm-up (page-in, BLAS threads)
+    t0 = time.perf_counter()
+    for t in range(2, 2 + steps):
+        o.train_step(p, m, v, t, src, ctx, tgt, 1e-4, cfg)
+    dt = time.perf_counter() - t0
+    return {"value": batch * steps / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from imitation_from_observation_amd.dp import DataParallelTrainer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = args.batch
+    trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234)
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    frames = [torch.randint(0, 256, (B, H, W, 3), device="cuda", generator=g, dtype=torch.uint8) for _ in range(3)]
+    src, ctx, tgt = (f.float() / 127.5 - 1.0 for f in frames)      # synthetic frames, train_script.py:16-19 scaling
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(src, ctx, tgt, lr=1e-4)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(src, ctx, tgt, lr=1e-4)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    scal = trainer.scalars()
+
+    ms = 1e3 * dt / args.steps
+    value = args.steps * B * world / dt
+    line = {
+        "metric": "frames/sec fwd+bwd+Adam, 64x64x3, batch 256 per GPU",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "ContextSkipNew 64x64x3 fwd+bwd+Adam, batch 256/GPU (BASELINE configs[1])",
+                   "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
+                   "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
+        "loss_after": scal["loss"],
+        "step_rates": {
+            "tflops_f32": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / 1e12,
+            "frac_f32_mfma_peak": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / PEAK_F32_MFMA,
+            "algorithmic_hbm_GBps": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / 1e9,
+            "frac_hbm_peak": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / PEAK_HBM,
+        },
+    }
+    if rank == 0:
+        # dominant kernel: timed with HIP events on the handle's stream
+        tr = trainer.translator
+        ents = tr.profile_step(src.data_ptr(), ctx.data_ptr(), tgt.data_ptr(), B, lr=1e-4, iters=args.kernel_iters)
+        tab = tr.kernel_table(ents)
+        kname, k = next(iter(tab.items()))          # the kernel with the most time in a step
+        per_launch_ms = k["ms"] / k["launches"]
+        ach = k["flops"] / (k["ms"] * 1e-3)
+        line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "launches_per_step": k["launches"],
+                            "avg_ms_per_launch": per_launch_ms, "flops_per_launch": k["flops"] / k["launches"],
+                            "share_of_step_ms": k["ms"] / sum(t["ms"] for t in tab.values()), "traffic": None}
+        line["kernels"] = {n: {"ms": round(t["ms"], 4), "launches": t["launches"],
+                               "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None}
+                           for n, t in tab.items()}
+        if os.environ.get("BENCH_LAYER_TABLE"):
+            with open(os.environ["BENCH_LAYER_TABLE"], "w") as f:
+                for e in ents:
+                    tf = e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else 0
+                    f.write(f"{e['name']:34s} {e['kernel']:34s} {e['ms']:9.4f} ms {tf:8.2f} TF/s\n")
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(batch=32, steps=3)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

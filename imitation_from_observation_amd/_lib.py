@@ -14,6 +14,11 @@ class CtxConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("variant", "H", "W", "C", "df_dim", "featsize", "max_batch", "reserved")]
 
 
+class CtxProfEntry(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 56), ("kernel", ctypes.c_char * 40), ("flops", ctypes.c_double),
+                ("ms", ctypes.c_float), ("reserved", ctypes.c_float)]
+
+
 class CtxError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libctxtrans error {code}: {msg}")
@@ -60,6 +65,8 @@ SIGNATURES = {
     "ctx_stream": (_P, [_P]),
     "ctx_sync": (_c.c_int, [_P]),
     "ctx_dev_outputs": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P)]),
+    "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
+                                    _c.POINTER(_c.c_int)]),
     "ctx_debug_read": (_c.c_int, [_P, _c.c_char_p, _F, _c.c_size_t]),
 }
 

@@ -73,7 +73,15 @@ struct ctx_handle {
     float *dout = nullptr, *dE[4] = {}, *dSk[4] = {}, *dDz = nullptr, *dsim2 = nullptr;
     float *dth0 = nullptr, *dcz = nullptr, *dS[5] = {}, *dC[5] = {};
     float *scratch = nullptr, *slab = nullptr, *scalars = nullptr;
+    float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
     int64_t slab_floats = 0;
+
+    // per-op profiling (ctx_profile_step): HIP events around every launch group
+    bool prof_on = false;
+    int prof_cursor = 0;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<ctx_prof_entry> prof_entries;
+    std::vector<double> prof_ms;
 
     float* Wp(const char* name) const { return arena + find(name); }
     float* Gp(const char* name) const { return arena + Ppad + find(name); }
@@ -96,6 +104,33 @@ int fail(ctx_handle* h, int code, const char* fmt, ...) {
     else g_create_error = buf;
     return code;
 }
+
+// RAII timer of one launch group; a no-op unless ctx_profile_step is running
+struct ProfScope {
+    ctx_handle* h;
+    int idx = -1;
+    ProfScope(ctx_handle* h_, const std::string& name, const char* kernel, double flops) : h(h_) {
+        if (!h->prof_on) return;
+        idx = h->prof_cursor++;
+        if ((int)h->prof_entries.size() <= idx) {
+            ctx_prof_entry e{};
+            snprintf(e.name, sizeof e.name, "%s", name.c_str());
+            snprintf(e.kernel, sizeof e.kernel, "%s", kernel);
+            e.flops = flops;
+            h->prof_entries.push_back(e);
+            h->prof_ms.push_back(0.0);
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            h->prof_ev.push_back(a);
+            h->prof_ev.push_back(b);
+        }
+        (void)hipEventRecord(h->prof_ev[2 * idx], h->stream);
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(h->prof_ev[2 * idx + 1], h->stream);
+    }
+};
 
 #define HIP_TRY(h, expr)                                                                          \
     do {                                                                                          \
@@ -214,10 +249,11 @@ int alloc_buffers(ctx_handle* h) {
         TRY(dev_alloc(h, &h->dE[k], 2 * B * pix * ch));
     }
     TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
+    TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD));
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
     int64_t maxc = std::max<int64_t>(h->D0, F);
     maxc = std::max<int64_t>(maxc, 16 * d);
-    TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, COLSUM_SPLITS * maxc)));
+    TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
     h->slab_floats = 32ll << 20;
     TRY(dev_alloc(h, &h->slab, h->slab_floats));
     TRY(dev_alloc(h, &h->scalars, 4));
@@ -226,14 +262,28 @@ int alloc_buffers(ctx_handle* h) {
 
 SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats}; }
 
+const char* const K_CONV = "igemm<ConvGather,Plain>";
+const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
+const char* const K_WGRAD = "igemm<WgradBig,WgradSmall>";
+const char* const K_C3FWD = "igemm<C3Gather,C3Weights>";
+const char* const K_C3WGRAD = "igemm<C3WgradBig,WgradSmall>";
+const char* const K_FCFWD = "igemm<KmPlain,NmPlain>";
+const char* const K_FCDX = "igemm<KmPlain,KmPlain>";
+const char* const K_FCDW = "igemm<NmPlain,NmPlain>";
+const char* const K_CONVT3 = "convt3_gather";
+const char* const K_CONVT3P = "igemm<Cat2,KmPlain>";
+const char* const K_COLSUM = "colsum";
+const char* const K_EW = "elementwise";
+
 // ---- layer launch helpers -------------------------------------------------------------------------
 NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K}; }
 KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC}; }
 
 // y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
-void conv_layer(ctx_handle* h, const float* x, int nimg, int hb, int wb, int ca, const float* w, const float* b, float* y,
-                int cb) {
+void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
+                const float* b, float* y, int cb) {
     const int hs = hb / 2, ws = wb / 2, R = nimg * hs * ws;
+    ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
     if (ca == 3) conv3_fwd(h->stream, KmC3Gather{x, hb, wb, hs, ws, R}, NmC3Weights{w, cb}, ep, R, cb, ws_of(h));
@@ -241,23 +291,34 @@ void conv_layer(ctx_handle* h, const float* x, int nimg, int hb, int wb, int ca,
 }
 
 // y = act(x W + b), x possibly [x0 | x1] along K
-void fc_layer(ctx_handle* h, const KmPlain& a, int M, int K, const float* w, const float* b, int N, int lrelu, float* y) {
+void fc_layer(ctx_handle* h, const std::string& name, const KmPlain& a, int M, int K, const float* w, const float* b, int N,
+              int lrelu, float* y) {
+    ProfScope ps(h, name + " fwd", K_FCFWD, 2.0 * M * K * N);
     Epi ep;
     ep.out1 = y; ep.ld1 = N; ep.bias = b; ep.lrelu = lrelu;
     gemm_fc_fwd(h->stream, a, nm(w, N, N, K), ep, M, N, K / KC, ws_of(h));
 }
 
 // dx = dy W^T (+ epilogue): dy [M, N], W [K, N] -> dx [M, K]
-void fc_dx(ctx_handle* h, const float* dy, int M, int N, const float* w, int K, Epi ep) {
+void fc_dx(ctx_handle* h, const std::string& name, const float* dy, int M, int N, const float* w, int K, Epi ep) {
+    ProfScope ps(h, name + " dx", K_FCDX, 2.0 * M * K * N);
     gemm_fc_dx(h->stream, km(dy, N, M, N), km(w, N, K, N), ep, M, K, N / KC, ws_of(h));
 }
 
 // dW = x^T dy, db = colsum(dy): x [M rows] possibly [x0 | x1] along features
-void fc_dw(ctx_handle* h, const NmPlain& x, int K, const float* dy, int M, int N, float* dw, float* db) {
-    Epi ep;
-    ep.out1 = dw; ep.ld1 = N;
-    gemm_fc_dw(h->stream, x, nm(dy, N, N, M), ep, K, N, (M + KC - 1) / KC, ws_of(h));
-    colsum(h->stream, dy, M, N, h->scratch, db);
+void bias_grad(ctx_handle* h, const std::string& name, const float* dy, int64_t rows, int C, float* db) {
+    ProfScope ps(h, name + " db", K_COLSUM, 0.0);
+    colsum(h->stream, dy, rows, C, h->scratch, db);
+}
+
+void fc_dw(ctx_handle* h, const std::string& name, const NmPlain& x, int K, const float* dy, int M, int N, float* dw, float* db) {
+    {
+        ProfScope ps(h, name + " dw", K_FCDW, 2.0 * M * K * N);
+        Epi ep;
+        ep.out1 = dw; ep.ld1 = N;
+        gemm_fc_dw(h->stream, x, nm(dy, N, N, M), ep, K, N, (M + KC - 1) / KC, ws_of(h));
+    }
+    bias_grad(h, name, dy, M, N, db);
 }
 
 struct Scope {
@@ -280,18 +341,19 @@ Scope scope_of(ctx_handle* h, const std::string& sc) {
 }
 
 // arm_shaping.py:1282-1288 / :1290-1307: four conv+lrelu, h4_lin+lrelu, hz_lin (+lrelu for `conv`)
-void encoder_fwd(ctx_handle* h, const Scope& sc, const float* x, int nimg, float* const act[5], float* z, int z_lrelu) {
+void encoder_fwd(ctx_handle* h, const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* z,
+                 int z_lrelu) {
     const int d = h->d, F = h->F;
     const float* in = x;
     int ca = 3;
     for (int k = 0; k < 4; ++k) {
-        conv_layer(h, in, nimg, h->hh[k], h->ww[k], ca, sc.w[k], sc.b[k], act[k], d << k);
+        conv_layer(h, scn + "/h" + std::to_string(k) + "_conv", in, nimg, h->hh[k], h->ww[k], ca, sc.w[k], sc.b[k], act[k], d << k);
         in = act[k];
         ca = d << k;
     }
     const int K3 = h->hh[4] * h->ww[4] * 8 * d;   // NHWC flatten, arm_shaping.py:1287
-    fc_layer(h, km(act[3], K3, nimg, K3), nimg, K3, sc.w4, sc.b4, F, 1, act[4]);
-    fc_layer(h, km(act[4], F, nimg, F), nimg, F, sc.wz, sc.bz, F, z_lrelu, z);
+    fc_layer(h, scn + "/h4_lin", km(act[3], K3, nimg, K3), nimg, K3, sc.w4, sc.b4, F, 1, act[4]);
+    fc_layer(h, scn + "/hz_lin", km(act[4], F, nimg, F), nimg, F, sc.wz, sc.bz, F, z_lrelu, z);
 }
 
 enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
@@ -304,17 +366,17 @@ void forward(ctx_handle* h, int B, Mode mode) {
     const int64_t npi = h->npi;
     const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
     float* src_z = h->Z + 2ll * B * F;
-    if (mode == MODE_TRAIN) encoder_fwd(h, st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
-    else encoder_fwd(h, st, h->img + B * npi, B, h->s, src_z, 1);
+    if (mode == MODE_TRAIN) encoder_fwd(h, "conv", st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
+    else encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
     if (mode == MODE_ENCODE) return;
-    encoder_fwd(h, cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+    encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
     // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
     KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC};
-    fc_layer(h, tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
-    fc_layer(h, km(h->th0, F, B, F), B, F, h->Wp("translate/trans_z/Matrix"), h->Wp("translate/trans_z/bias"), F, 0, h->Z);
+    fc_layer(h, "translate/trans_h0", tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
+    fc_layer(h, "translate/trans_z", km(h->th0, F, B, F), B, F, h->Wp("translate/trans_z/Matrix"), h->Wp("translate/trans_z/bias"), F, 0, h->Z);
     // decoder (arm_shaping.py:1321-1330, :1334-1343)
     const int nd = mode == MODE_TRAIN ? 2 * B : B;
-    fc_layer(h, km(h->Z, F, nd, F), nd, F, h->Wp("deconv/d_h0_lin/Matrix"), h->Wp("deconv/d_h0_lin/bias"), (int)h->D0, 1, h->dz);
+    fc_layer(h, "deconv/d_h0_lin", km(h->Z, F, nd, F), nd, F, h->Wp("deconv/d_h0_lin/Matrix"), h->Wp("deconv/d_h0_lin/bias"), (int)h->D0, 1, h->dz);
     const float* dec = h->dz;
     for (int k = 1; k <= 4; ++k) {
         const int hs = h->hh[5 - k], ws = h->ww[5 - k];      // input grid of d_hk
@@ -324,15 +386,21 @@ void forward(ctx_handle* h, int B, Mode mode) {
         const float* w = h->Wp((nm_ + "/w").c_str());
         const float* b = h->Wp((nm_ + "/biases").c_str());
         const float* skip = h->c[4 - k];
+        const double fl = 2.0 * nd * hs * ws * 25 * (c1 + c2) * ca;
         if (k < 4) {
             const int R = nd * hs * ws;
+            ProfScope ps(h, nm_ + " fwd", K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
             convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R},
                       KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC}, ep, R, ca, ws_of(h));
             dec = h->e[k];
         } else {
-            convt3_fwd(h->stream, ConvT3Args{dec, c1, c1, skip, c2, c2, B, w, b, h->out, nd, hs, ws});
+            const int R = nd * hs * ws;
+            { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl);
+              convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC}, w, c1 + c2, h->P3, R, ws_of(h)); }
+            { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
+              convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
         }
     }
 }
@@ -346,7 +414,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     const SplitWs ws = ws_of(h);
     float* tgt_z = h->Z + (int64_t)B * F;
     float* src_z = h->Z + 2ll * B * F;
-    losses(s, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+    {
+        ProfScope ps(h, "losses", K_EW, 0.0);
+        losses(s, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+    }
 
     // ---- decoder, both passes at once (batch 2B)
     const float* dy = h->dout;
@@ -359,7 +430,8 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         const float* w = h->Wp((nm_ + "/w").c_str());
         const float* dec_in = k > 1 ? h->e[k - 1] : h->dz;      // decoder half of the concat input
         float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
-        colsum(s, dy, (int64_t)2 * B * hb * wb, ca, h->scratch, h->Gp((nm_ + "/biases").c_str()));
+        bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
+        const double fl = 2.0 * R * 25 * cb * ca;
         NmWgradSmall small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, R};
         Epi eg;
         eg.out1 = h->Gp((nm_ + "/w").c_str()); eg.ld1 = cb;
@@ -369,61 +441,65 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
         if (ca == 3) {
-            conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, hs, wsm, R}, small, eg, cb, ws);
-            conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R}, NmC3Weights{w, cb}, ed, R, cb, ws);
+            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, hs, wsm, R}, small, eg, cb, ws); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R}, NmC3Weights{w, cb}, ed, R, cb, ws); }
         } else {
-            conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws);
-            conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws);
+            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
+              conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
         }
         dy = d_dec;
     }
     // d_h0_lin: input Z[0:2B] = [trans_z | tgt_z]; simloss adds +-c(trans_z - tgt_z) to its gradient
     {
         const int D0 = (int)h->D0;
-        fc_dw(h, nm(h->Z, F, F, 2 * B), F, h->dDz, 2 * B, D0, h->Gp("deconv/d_h0_lin/Matrix"), h->Gp("deconv/d_h0_lin/bias"));
+        fc_dw(h, "deconv/d_h0_lin", nm(h->Z, F, F, 2 * B), F, h->dDz, 2 * B, D0, h->Gp("deconv/d_h0_lin/Matrix"), h->Gp("deconv/d_h0_lin/bias"));
         Epi ep;
         ep.out1 = h->dZ; ep.ld1 = F; ep.add1 = h->dsim2; ep.lda1 = F;
-        fc_dx(h, h->dDz, 2 * B, D0, h->Wp("deconv/d_h0_lin/Matrix"), F, ep);
+        fc_dx(h, "deconv/d_h0_lin", h->dDz, 2 * B, D0, h->Wp("deconv/d_h0_lin/Matrix"), F, ep);
     }
     // ---- translate MLP: d trans_z = dZ[0:B]
     {
-        fc_dw(h, nm(h->th0, F, F, B), F, h->dZ, B, F, h->Gp("translate/trans_z/Matrix"), h->Gp("translate/trans_z/bias"));
+        fc_dw(h, "translate/trans_z", nm(h->th0, F, F, B), F, h->dZ, B, F, h->Gp("translate/trans_z/Matrix"), h->Gp("translate/trans_z/bias"));
         Epi e1;
         e1.out1 = h->dth0; e1.ld1 = F; e1.mask = h->th0; e1.ldm = F;
-        fc_dx(h, h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
+        fc_dx(h, "translate/trans_z", h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
         NmPlain tcat{src_z, F, h->cz, F, F, 2 * F, B};
-        fc_dw(h, tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
+        fc_dw(h, "translate/trans_h0", tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
         Epi e2;   // d concat: cols < F -> d src_z (row block 2 of dZ), cols >= F -> d ctx_z
         e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;
-        fc_dx(h, h->dth0, B, F, h->Wp("translate/trans_h0/Matrix"), 2 * F, e2);
+        fc_dx(h, "translate/trans_h0", h->dth0, B, F, h->Wp("translate/trans_h0/Matrix"), 2 * F, e2);
     }
     // ---- encoders
-    auto encoder_bwd = [&](const Scope& sc, const float* x, int nimg, float* const act[5], float* dzp, float* const dA[5],
+    auto encoder_bwd = [&](const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* dzp, float* const dA[5],
                            bool with_skips) {
         const int K3 = h->hh[4] * h->ww[4] * 8 * d;
-        fc_dw(h, nm(act[4], F, F, nimg), F, dzp, nimg, F, sc.gwz, sc.gbz);
+        fc_dw(h, scn + "/hz_lin", nm(act[4], F, F, nimg), F, dzp, nimg, F, sc.gwz, sc.gbz);
         Epi e4;
         e4.out1 = dA[4]; e4.ld1 = F; e4.mask = act[4]; e4.ldm = F;
-        fc_dx(h, dzp, nimg, F, sc.wz, F, e4);
-        fc_dw(h, nm(act[3], K3, K3, nimg), K3, dA[4], nimg, F, sc.gw4, sc.gb4);
+        fc_dx(h, scn + "/hz_lin", dzp, nimg, F, sc.wz, F, e4);
+        fc_dw(h, scn + "/h4_lin", nm(act[3], K3, K3, nimg), K3, dA[4], nimg, F, sc.gw4, sc.gb4);
         Epi e3;
         e3.out1 = dA[3]; e3.ld1 = K3; e3.mask = act[3]; e3.ldm = K3;
         if (with_skips) { e3.add1 = h->dSk[3]; e3.lda1 = K3; e3.add2 = h->dSk[3] + (int64_t)B * K3; e3.lda2 = K3; }
-        fc_dx(h, dA[4], nimg, F, sc.w4, K3, e3);
+        fc_dx(h, scn + "/h4_lin", dA[4], nimg, F, sc.w4, K3, e3);
         for (int k = 3; k >= 0; --k) {
             const int hb = h->hh[k], wb = h->ww[k], hs = hb / 2, wsm = wb / 2;
             const int ca = k ? d << (k - 1) : 3, cb = d << k;
             const int R = nimg * hs * wsm;
             const float* xin = k ? act[k - 1] : x;
-            colsum(s, dA[k], R, cb, h->scratch, sc.gb[k]);
+            const std::string ln = scn + "/h" + std::to_string(k) + "_conv";
+            const double fl = 2.0 * R * 25 * ca * cb;
+            bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
             NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, R};
             Epi eg;
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
             if (k == 0) {
+                ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
                 conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, hs, wsm, R}, small, eg, cb, ws);
                 break;   // no gradient w.r.t. the frame
             }
-            conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws);
+            { ProfScope ps(h, ln + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws); }
             // input gradient = conv2d_transpose of dA[k] with the same filter read as [5,5,ca,cb]
             Epi ed;
             ed.out1 = dA[k - 1]; ed.ld1 = ca; ed.mask = act[k - 1]; ed.ldm = ca;
@@ -431,16 +507,17 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add1 = h->dSk[k - 1]; ed.lda1 = ca;
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
+            ProfScope ps(h, ln + " dx", K_CONVT, fl);
             convt_fwd(s, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R}, KmConvTWeights{sc.w[k], ca, cb, cb / KC},
                       ed, R, ca, ws);
         }
     };
     // `conv` on [tgt | src]: code gradients are rows [B, 3B) of dZ; hz_lin has an lrelu
     float* dSz = h->dZ + (int64_t)B * F;
-    lrelu_mask(s, dSz, tgt_z, 2ll * B * F);
-    encoder_bwd(scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false);
+    { ProfScope ps(h, "conv/hz_lin lrelu'", K_EW, 0.0); lrelu_mask(s, dSz, tgt_z, 2ll * B * F); }
+    encoder_bwd("conv", scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false);
     // `conv_context`: linear hz_lin; its h0..h3 also feed both decoder passes as skips
-    encoder_bwd(scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+    encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
     h->have_grads = true;
 }
 
@@ -461,6 +538,7 @@ int adam_step(ctx_handle* h, float lr) {
     const double b1 = 0.9, b2 = 0.999;
     h->adam_t += 1;
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t));
+    ProfScope ps(h, "adam", "adam", 0.0);
     adam(h->stream, h->arena, h->arena + h->Ppad, h->arena + 2 * h->Ppad, h->arena + 3 * h->Ppad, h->Ppad, (float)lr_t,
          (float)b1, (float)b2, 1e-8f);
     return CTX_OK;
@@ -557,6 +635,7 @@ void ctx_destroy(ctx_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -771,6 +850,40 @@ int ctx_eval(ctx_handle* h, const float* src, const float* ctxf, const float* tg
     if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
     if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
     return finish(h);
+}
+
+int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr, int iters,
+                     ctx_prof_entry* entries, int max_entries, int* n_entries) {
+    TRY(check_B(h, B));
+    if (!d_src || !d_ctx || !d_tgt || iters <= 0 || !n_entries) return fail(h, CTX_E_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    for (auto& m : h->prof_ms) m = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+        h->prof_on = true;
+        h->prof_cursor = 0;
+        forward(h, B, MODE_TRAIN);
+        backward(h, B, B);
+        const int rc = adam_step(h, lr);
+        h->prof_on = false;
+        if (rc != CTX_OK) return rc;
+        TRY(finish(h));
+        for (int i = 0; i < h->prof_cursor; ++i) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+            h->prof_ms[i] += ms;
+        }
+    }
+    h->last_B = B;
+    *n_entries = h->prof_cursor;
+    for (int i = 0; i < h->prof_cursor && i < max_entries; ++i) {
+        entries[i] = h->prof_entries[i];
+        entries[i].ms = (float)(h->prof_ms[i] / iters);
+    }
+    return CTX_OK;
 }
 
 // Test hook: copy an internal device buffer to the host (names: img Z dZ cz th0 dz out dout dDz dsim2

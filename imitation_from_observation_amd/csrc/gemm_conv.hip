@@ -10,6 +10,13 @@ void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, E
     // no split-K here: the four parity classes have different K extents and M is the pixel count
     launch_igemm(s, a, b, ep, M, N, 4, 0, ws);
 }
+void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws) {
+    // B[k][n] = w[ky,kx,c,k] with n = (ky*5+kx)*3+c: the filter itself, rows n contiguous in k
+    KmPlain b{w, cb, nullptr, 0, cb, 75, cb / KC};
+    Epi ep;
+    ep.out1 = P; ep.ld1 = P3_LD;
+    launch_igemm(s, a, b, ep, M, 75, 1, 0, ws);
+}
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, 3, ws);
 }

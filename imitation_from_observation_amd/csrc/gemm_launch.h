@@ -29,7 +29,7 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         int64_t cap_ws = ws.slab_floats / ((int64_t)nprob * M * N);
         int64_t n = want < cap_k ? want : cap_k;
         if (n > cap_ws) n = cap_ws;
-        if (n > 64) n = 64;
+        if (n > 256) n = 256;
         if (n > 1) nsplit = (int)n;
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;

@@ -215,6 +215,30 @@ struct KmC3Gather {
     }
 };
 
+// Per-pixel channel vectors of the decoder's concat input [s1 | s2]: row m = pixel (img,i,j), k =
+// channel; s2 is the ctx skip (image index img % nmod2).  Used by the d_h4 scatter product.
+struct KmCat2 {
+    static constexpr bool KM = true;
+    const float* s1; int64_t ld1; int c1;
+    const float* s2; int64_t ld2; int nmod2;
+    int hsws;        // pixels per image
+    int R;           // pixels
+    int cps;         // (c1 + c2) / 32
+    struct Ctx { int64_t p1, p2; bool ok; };
+    __device__ int nchunks_of(int) const { return cps; }
+    __device__ void prep(int, int row, Ctx& c) const {
+        c.ok = row < R;
+        const int n = row / hsws, rem = row - n * hsws;
+        c.p1 = (int64_t)row * ld1;
+        c.p2 = ((int64_t)(n % nmod2) * hsws + rem) * ld2;
+    }
+    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
+        if (!c.ok) return zero4();
+        const int k = chunk * KC + k4;
+        return k < c1 ? ldg4(s1 + c.p1 + k) : ldg4(s2 + c.p2 + (k - c1));
+    }
+};
+
 // Plain k-major matrix V[k][r], optionally split along r into two buffers; ragged K allowed.
 struct NmPlain {
     static constexpr bool KM = false;

@@ -29,74 +29,41 @@ void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int ns
 }
 
 // ------------------------------------------------------------------------------------------------
-// conv2d_transpose 5x5 s2 to 3 output channels (d_h4, arm_shaping.py:1329-1330, :1342-1343).
-// N = 3 is far below an MFMA tile, so this one is a direct VALU kernel: a block owns one output
-// parity class (py,px) -- all its lanes then use the same taps, whose filter slices sit in LDS and
-// are read at wave-uniform addresses (broadcast).  A thread produces 4 horizontally adjacent output
-// pixels of its class x 3 channels, so each filter read feeds 4 pixels.
-//   out[n, 2i'+py, 2j'+px, c] = b[c] + sum_{sy,sx,k} in[n, i'+py-sy, j'+px-sx, k] * w[1-py+2sy, 1-px+2sx, c, k]
+// conv2d_transpose 5x5 s2 to 3 output channels (d_h4, arm_shaping.py:1329-1330, :1342-1343), step 2:
+//   out[n, y, x, c] = b[c] + sum over taps with y = 2i+ky-1, x = 2j+kx-1 of P[(n,i,j)][(ky*5+kx)*3+c]
+// One thread per output pixel; taps are added in a fixed order.  HBM/L2-bound: 4-9 x 12 B gathers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void convt3_fwd_kernel(const ConvT3Args a) {
-    extern __shared__ __attribute__((aligned(16))) float wl[];   // [ntaps][3][cb]
-    const int py = blockIdx.y >> 1, px = blockIdx.y & 1;
-    const int nty = 2 + py, ntx = 2 + px, cb = a.c1 + a.c2;
-    for (int idx = threadIdx.x * 4; idx < nty * ntx * 3 * cb; idx += NTHREADS * 4) {
-        const int k = idx % cb, t = idx / cb, c = t % 3, tap = t / 3;
-        const int sy = tap / ntx, sx = tap - sy * ntx;
-        const int ky = 1 - py + 2 * sy, kx = 1 - px + 2 * sx;
-        *reinterpret_cast<float4*>(&wl[idx]) = ldg4(a.w + ((int64_t)((ky * 5 + kx) * 3 + c)) * cb + k);
-    }
-    __syncthreads();
-    const int wq = a.ws >> 2;
-    const int64_t gid = (int64_t)blockIdx.x * NTHREADS + threadIdx.x;
-    if (gid >= (int64_t)a.nimg * a.hs * wq) return;
-    const int jq = (int)(gid % wq);
-    const int64_t t = gid / wq;
-    const int ip = (int)(t % a.hs), n = (int)(t / a.hs);
-    float acc[4][3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q][0] = acc[q][1] = acc[q][2] = 0.f;
-    for (int sy = 0; sy < nty; ++sy) {
-        const int i = ip + py - sy;
-        if ((unsigned)i >= (unsigned)a.hs) continue;
-        for (int sx = 0; sx < ntx; ++sx) {
-            const int jb = 4 * jq + px - sx;
-            const float* wt = wl + (sy * ntx + sx) * 3 * cb;
-            bool ok[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ok[q] = (unsigned)(jb + q) < (unsigned)a.ws;
-            const float* r1 = a.s1 + (((int64_t)n * a.hs + i) * a.ws + jb) * a.ld1;
-            const float* r2 = a.s2 + (((int64_t)(n % a.nmod2) * a.hs + i) * a.ws + jb) * a.ld2;
-            for (int k = 0; k < cb; k += 4) {
-                const float4 w0 = *reinterpret_cast<const float4*>(wt + k);
-                const float4 w1 = *reinterpret_cast<const float4*>(wt + cb + k);
-                const float4 w2 = *reinterpret_cast<const float4*>(wt + 2 * cb + k);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!ok[q]) continue;
-                    const float4 x = k < a.c1 ? ldg4(r1 + q * a.ld1 + k) : ldg4(r2 + q * a.ld2 + (k - a.c1));
-                    acc[q][0] += x.x * w0.x + x.y * w0.y + x.z * w0.z + x.w * w0.w;
-                    acc[q][1] += x.x * w1.x + x.y * w1.y + x.z * w1.z + x.w * w1.w;
-                    acc[q][2] += x.x * w2.x + x.y * w2.y + x.z * w2.z + x.w * w2.w;
-                }
+__global__ __launch_bounds__(NTHREADS) void convt3_gather_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int nimg, int hs, int ws) {
+    const int wb = 2 * ws, hb = 2 * hs;
+    const int64_t total = (int64_t)nimg * hb * wb;
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
+        const int x = (int)(idx % wb);
+        const int64_t t = idx / wb;
+        const int y = (int)(t % hb), n = (int)(t / hb);
+        const int py = y & 1, px = x & 1, ip = y >> 1, jp = x >> 1;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int sy = 0; sy < 2 + py; ++sy) {
+            const int i = ip + py - sy, ky = 1 - py + 2 * sy;
+            if ((unsigned)i >= (unsigned)hs) continue;
+            for (int sx = 0; sx < 2 + px; ++sx) {
+                const int j = jp + px - sx, kx = 1 - px + 2 * sx;
+                if ((unsigned)j >= (unsigned)ws) continue;
+                const float* r = P + (((int64_t)n * hs + i) * ws + j) * P3_LD + (ky * 5 + kx) * 3;
+                a0 += r[0]; a1 += r[1]; a2 += r[2];
             }
         }
-    }
-    const float b0 = a.bias[0], b1 = a.bias[1], b2 = a.bias[2];
-    float* o = a.out + (((int64_t)n * (2 * a.hs) + 2 * ip + py) * (2 * a.ws) + 2 * (4 * jq) + px) * 3;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        o[q * 6 + 0] = acc[q][0] + b0;
-        o[q * 6 + 1] = acc[q][1] + b1;
-        o[q * 6 + 2] = acc[q][2] + b2;
+        float* o = out + idx * 3;
+        o[0] = a0 + b0; o[1] = a1 + b1; o[2] = a2 + b2;
     }
 }
 
-void convt3_fwd(hipStream_t s, const ConvT3Args& a) {
-    const int64_t threads = (int64_t)a.nimg * a.hs * (a.ws / 4);
-    dim3 grid((unsigned)((threads + NTHREADS - 1) / NTHREADS), 4);
-    const size_t lds = (size_t)9 * 3 * (a.c1 + a.c2) * sizeof(float);
-    hipLaunchKernelGGL(convt3_fwd_kernel, grid, dim3(NTHREADS), lds, s, a);
+void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {
+    const int64_t total = (int64_t)nimg * 4 * hs * ws;
+    int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(convt3_gather_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, P, bias, out, nimg, hs, ws);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,41 +181,82 @@ void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int6
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bias gradient: column sums of a row-major [rows, C] gradient.  Stage 1: a block covers 64 columns
-// x one row slice (4 row lanes, coalesced 256-B row reads); stage 2 adds the slices in fixed order.
+// Bias gradient: column sums of a row-major [rows, C] gradient, HBM-bound.  Stage 1: float4 columns;
+// a block covers min(C/4, 256) float4-columns x (256 / that) row lanes and walks its row slab with
+// coalesced full-row reads; row lanes are combined through LDS.  Stage 2 adds the slabs in fixed
+// order => deterministic.  C == 3 (the frame gradient) has its own flat kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int C,
+__global__ __launch_bounds__(NTHREADS) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int C, int tpr,
                                                                   int64_t rows_per, float* __restrict__ part) {
-    __shared__ float sh[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    __shared__ float4 sh[NTHREADS];
+    const int rpb = NTHREADS / tpr;                       // row lanes per block
+    const int rl = threadIdx.x / tpr, cq = threadIdx.x - rl * tpr;
+    const int c4 = blockIdx.x * tpr + cq;                 // float4 column
     const int64_t r0 = (int64_t)blockIdx.y * rows_per;
     int64_t r1 = r0 + rows_per;
     if (r1 > rows) r1 = rows;
-    float acc = 0.f;
-    if (c < C)
-        for (int64_t r = r0 + rl; r < r1; r += 4) acc += x[r * C + c];
-    sh[rl][threadIdx.x & 63] = acc;
+    float4 acc = zero4();
+    if (rl < rpb && c4 * 4 < C)
+        for (int64_t r = r0 + rl; r < r1; r += rpb) {
+            const float4 v = ldg4(x + r * C + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    sh[threadIdx.x] = acc;
     __syncthreads();
-    if (rl == 0 && c < C) part[(int64_t)blockIdx.y * C + c] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (rl == 0 && c4 * 4 < C) {
+        for (int k = 1; k < rpb; ++k) {
+            const float4 v = sh[k * tpr + cq];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c4 * 4) = acc;
+    }
 }
 
-__global__ __launch_bounds__(NTHREADS) void colsum_final_kernel(const float* __restrict__ part, int nsl, int C,
+// C == 3: the array is a flat run of (c0,c1,c2) triples; a thread eats 12 floats = 4 pixels at a time
+__global__ __launch_bounds__(NTHREADS) void colsum3_partial_kernel(const float* __restrict__ x, int64_t n12,
+                                                                   float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int64_t g = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; g < n12; g += (int64_t)gridDim.x * NTHREADS) {
+        const float4 a = ldg4(x + g * 12), b = ldg4(x + g * 12 + 4), c = ldg4(x + g * 12 + 8);
+        s0 += a.x + a.w + b.z + c.y;
+        s1 += a.y + b.x + b.w + c.z;
+        s2 += a.z + b.y + c.x + c.w;
+    }
+    const float r0 = block_sum(s0, sh), r1 = block_sum(s1, sh), r2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x * 4 + 0] = r0; part[blockIdx.x * 4 + 1] = r1; part[blockIdx.x * 4 + 2] = r2; }
+}
+
+__global__ __launch_bounds__(NTHREADS) void colsum_final_kernel(const float* __restrict__ part, int nsl, int C, int ldp,
                                                                 float* __restrict__ out) {
     const int c = blockIdx.x * NTHREADS + threadIdx.x;
     if (c >= C) return;
     float acc = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) acc += part[(int64_t)sl * C + c];
+    for (int sl = 0; sl < nsl; ++sl) acc += part[(int64_t)sl * ldp + c];
     out[c] = acc;
 }
 
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out) {
-    int nsl = (int)((rows + 255) / 256);
+    if (C == 3) {                                          // rows is a multiple of 4 (H, W multiples of 16)
+        const int64_t n12 = rows / 4;
+        int nsl = (int)((n12 + NTHREADS * 8 - 1) / (NTHREADS * 8));
+        if (nsl > COLSUM_SPLITS) nsl = COLSUM_SPLITS;
+        if (nsl < 1) nsl = 1;
+        hipLaunchKernelGGL(colsum3_partial_kernel, dim3(nsl), dim3(NTHREADS), 0, s, x, n12, scratch);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(1), dim3(NTHREADS), 0, s, (const float*)scratch, nsl, 3, 4, out);
+        return;
+    }
+    const int c4 = C / 4;
+    const int tpr = c4 < NTHREADS ? c4 : NTHREADS;
+    const int rpb = NTHREADS / tpr;
+    int nsl = (int)((rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8));
     if (nsl > COLSUM_SPLITS) nsl = COLSUM_SPLITS;
     if (nsl < 1) nsl = 1;
     const int64_t rows_per = (rows + nsl - 1) / nsl;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nsl), dim3(NTHREADS), 0, s, x, rows, C, rows_per, scratch);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((c4 + tpr - 1) / tpr, nsl), dim3(NTHREADS), 0, s, x, rows, C, tpr, rows_per,
+                       scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + NTHREADS - 1) / NTHREADS), dim3(NTHREADS), 0, s,
-                       (const float*)scratch, nsl, C, out);
+                       (const float*)scratch, nsl, C, C, out);
 }
 
 // ------------------------------------------------------------------------------------------------

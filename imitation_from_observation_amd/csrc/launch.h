@@ -26,17 +26,12 @@ void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi e
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
 
-// conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330): direct VALU kernel.
-struct ConvT3Args {
-    const float* s1; int64_t ld1; int c1;   // decoder stream [nimg, hs, ws, c1]
-    const float* s2; int64_t ld2; int c2;   // ctx skip [nmod2, hs, ws, c2]
-    int nmod2;
-    const float* w;                         // [5][5][3][c1+c2]
-    const float* bias;                      // [3]
-    float* out;                             // [nimg, 2hs, 2ws, 3]
-    int nimg, hs, ws;
-};
-void convt3_fwd(hipStream_t s, const ConvT3Args& a);
+// conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
+// product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a
+// gather of the <= 9 taps that land on each output pixel (deterministic, no atomics).
+constexpr int P3_LD = 80;                   // row stride of P (75 used)
+void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);
+void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
 
 // (x * 1/255 - 0.5) * 2 in unfused f32 ops (rllab/sampler/base.py:116-119)
 void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
@@ -52,8 +47,8 @@ constexpr int LOSS_BLOCKS = 512;
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
             const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars);
 
-// db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * C floats
-constexpr int COLSUM_SPLITS = 128;
+// db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * max(C, 4) floats
+constexpr int COLSUM_SPLITS = 256;
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out);
 
 // g *= (act >= 0 ? 1 : 0.2)

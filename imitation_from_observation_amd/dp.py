@@ -1,0 +1,101 @@
+"""Data-parallel training of the translator: one process per GPU, `torch.distributed` (backend
+"nccl" = RCCL over xGMI) for the single exchange step of the path.
+
+The reference has no multi-GPU code; this is new functionality defined by
+SURVEY.md 8e: the global batch is split evenly, every rank holds a full replica + Adam state, and per
+step   local fwd/bwd  ->  SUM all-reduce of the flat f32 gradient arena  ->  identical local Adam.
+recon1/recon2 are sums over the batch (arm_shaping.py:1352-1353) so their gradients add across
+shards; simloss is a mean over (global batch x featsize) (arm_shaping.py:1345), so each shard divides
+its simloss gradient by the GLOBAL batch (the `sim_batch` argument of ctx_dev_forward_backward).
+
+`DataParallelTrainer` only sequences an *engine* and the collective, so the same code runs on the
+HIP engine (cuda tensors, RCCL) and -- in the CPU test-suite -- on a gloo group with a stand-in engine.
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+import torch.distributed as dist
+
+from .translator import Translator
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class HipEngine:
+    """The HIP translator on torch-owned device memory: torch allocates the [params|grads|m|v] arena
+    and owns the stream, libctxtrans enqueues its kernels on that stream, so RCCL calls issued through
+    torch.distributed are stream-ordered with them."""
+
+    def __init__(self, H, W, df_dim, featsize, max_batch, device, seed):
+        self.dev = torch.device("cuda", device)
+        n = Translator.arena_floats(H, W, df_dim, featsize)
+        self.arena = torch.zeros(n, device=self.dev, dtype=torch.float32)
+        self.stride = n // 4
+        # a dedicated torch stream (the legacy default stream has handle 0 = "make your own" in the C ABI)
+        self.stream = torch.cuda.Stream(self.dev)
+        self.translator = Translator(H, W, df_dim, featsize, max_batch, device=device,
+                                     stream=self.stream.cuda_stream, arena_ptr=self.arena.data_ptr())
+        self.translator.init_params(seed)
+        self.n_params = self.translator.n_params
+        self.params = self.arena[: self.stride]
+        self.grads = self.arena[self.stride: 2 * self.stride]
+        self._scal = torch.zeros(4, device=self.dev, dtype=torch.float32)
+
+    @staticmethod
+    def _ptr(t):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("frames must be contiguous float32 cuda tensors")
+        return t.data_ptr()
+
+    def forward_backward(self, src, ctx, tgt, sim_batch):
+        B = src.shape[0]
+        self.translator.dev_forward_backward(self._ptr(src), self._ptr(ctx), self._ptr(tgt), B, sim_batch)
+
+    def adam(self, lr):
+        self.translator.dev_adam(lr)
+
+    def scalars_tensor(self):
+        """{loss, simloss, recon1, recon2} of the last forward as a device tensor."""
+        sc = self.translator.dev_scalars()       # synchronises the handle's stream
+        self._scal.copy_(torch.tensor([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]], dtype=torch.float32))
+        return self._scal
+
+
+class DataParallelTrainer:
+    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, seed=1234, engine=None):
+        self.engine = engine or HipEngine(H, W, df_dim, featsize, max_batch, device, seed)
+        self.world = _world()
+        self.n_params = self.engine.n_params
+        if self.world > 1:
+            dist.broadcast(self.engine.params, src=0)       # replicas start identical
+        self.translator = getattr(self.engine, "translator", None)
+
+    def step(self, src, ctx, tgt, lr=1e-4):
+        """One data-parallel train step on this rank's shard (all ranks pass equal batch sizes)."""
+        B = src.shape[0]
+        stream = getattr(self.engine, "stream", None)
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world)
+            if self.world > 1:
+                # RCCL orders itself after the current stream = the stream the kernels run on
+                dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM)
+            self.engine.adam(lr)
+
+    def scalars(self):
+        """Global {loss, simloss, recon1, recon2} of the last step's forward pass."""
+        stream = getattr(self.engine, "stream", None)
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            return self._scalars()
+
+    def _scalars(self):
+        t = self.engine.scalars_tensor().clone()
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t[1] /= self.world                               # simloss: mean over equal shards
+            t[0] = t[1] + t[2] + t[3]
+        v = [float(x) for x in t.cpu()]
+        return dict(loss=v[0], simloss=v[1], recon1=v[2], recon2=v[3])

@@ -268,6 +268,26 @@ class Translator:
     def scalars_ptr(self):
         return self._lib.ctx_dev_scalar_buf(self._h)
 
+    def profile_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4, iters=5):
+        """Per-launch-group timing of a full train step (HIP events on the handle's stream).
+        Returns [dict(name, kernel, flops, ms)]."""
+        ents = (_lib.CtxProfEntry * 256)()
+        n = ctypes.c_int()
+        self._ck(self._lib.ctx_profile_step(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt),
+                                            B, float(lr), iters, ents, 256, ctypes.byref(n)))
+        return [dict(name=e.name.decode(), kernel=e.kernel.decode(), flops=e.flops, ms=e.ms) for e in ents[: n.value]]
+
+    @staticmethod
+    def kernel_table(entries):
+        """Groups profile_step entries by kernel: {kernel: dict(ms, flops, launches)}, ms-descending."""
+        tab = {}
+        for e in entries:
+            t = tab.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, launches=0))
+            t["ms"] += e["ms"]
+            t["flops"] += e["flops"]
+            t["launches"] += 1
+        return dict(sorted(tab.items(), key=lambda kv: -kv[1]["ms"]))
+
     def debug_read(self, name, n):
         out = np.empty(int(n), np.float32)
         self._ck(self._lib.ctx_debug_read(self._h, name.encode(), _fp(out), out.size))

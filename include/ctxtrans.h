@@ -142,6 +142,21 @@ int ctx_sync(ctx_handle* h);
 int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const float** input_z,
                     const float** translated_z);
 
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* One entry per launch group of a train step (a layer's forward, input gradient, filter gradient,
+ * bias gradient, the losses, Adam): HIP-event time on the handle's stream, averaged over `iters`
+ * full steps, plus the group's algorithmic FLOPs (2 per multiply-add, all 25 taps) and the kernel
+ * that executes it.  bench.py derives its `roofline` block from this. */
+typedef struct ctx_prof_entry {
+    char name[56];
+    char kernel[40];
+    double flops;
+    float ms;
+    float reserved;
+} ctx_prof_entry;
+int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B,
+                     float lr, int iters, ctx_prof_entry* entries, int max_entries, int* n_entries);
+
 /* ---- test hook ------------------------------------------------------------------------------- */
 /* Copies n floats of a named internal activation / gradient buffer to the host (bring-up and
  * parity tests only; names are listed in csrc/ctxtrans.cpp). */

@@ -18,6 +18,7 @@ def rel(a, b):
 
 
 def main(H=32, W=32, d=32, F=128, B=4, stddev=0.05):
+    stddev = 0.02 if d >= 64 else stddev
     cfg = o.SkipNewConfig(H=H, W=W, df_dim=d, gf_dim=d, featsize=F)
     p = o.init_params(cfg, 1234, np.float64, stddev=stddev)
     brng = np.random.default_rng(1)

@@ -1,0 +1,80 @@
+"""The C-ABI boundary without a GPU: libctxtrans.so loads, exports every symbol include/ctxtrans.h
+declares, the ctypes table matches the header, and the product path FAILS LOUDLY without a device
+(there is no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from imitation_from_observation_amd import _lib
+
+
+def header_functions(repo_root):
+    src = open(os.path.join(repo_root, "include", "ctxtrans.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol(built_lib, repo_root):
+    names = header_functions(repo_root)
+    assert len(names) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/ctxtrans.h but not exported"
+
+
+def test_ctypes_table_matches_header(built_lib, repo_root):
+    assert sorted(_lib.SIGNATURES) == header_functions(repo_root)
+
+
+def test_abi_version(built_lib):
+    assert built_lib.ctx_abi_version() == 1
+
+
+def test_param_total_is_the_references(built_lib):
+    from imitation_from_observation_amd import Translator
+    assert Translator.param_total(64, 64, 64, 1024) == 47_647_811
+    assert Translator.param_total(48, 48, 64, 1024) == 47_647_811 - 2 * (8192 - 4608) * 1024 - (8192 - 4608) * 1025
+    assert Translator.arena_floats(64, 64, 64, 1024) % 256 == 0
+
+
+@pytest.mark.parametrize("kw", [dict(H=60), dict(W=40), dict(df_dim=48), dict(featsize=100), dict(max_batch=0), dict(C=1),
+                                dict(variant=7)])
+def test_bad_config_is_rejected(built_lib, kw):
+    base = dict(variant=0, H=64, W=64, C=3, df_dim=64, featsize=1024, max_batch=4, reserved=0)
+    base.update(kw)
+    cfg = _lib.CtxConfig(**base)
+    assert built_lib.ctx_param_total_for(ctypes.byref(cfg)) == _lib.CTX_E_INVALID
+    h = ctypes.c_void_p()
+    assert built_lib.ctx_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == _lib.CTX_E_INVALID
+    assert not h.value
+    assert built_lib.ctx_last_error(None)
+
+
+def test_no_cpu_fallback(built_lib):
+    """On a box without a GPU the product path must refuse to run, not compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from imitation_from_observation_amd import CtxError, Translator
+    with pytest.raises(CtxError) as ei:
+        Translator(32, 32, 32, 128, max_batch=2)
+    assert ei.value.code == _lib.CTX_E_DEVICE
+    assert "no CPU path" in str(ei.value)
+
+
+def test_null_handle_calls_return_errors(built_lib):
+    assert built_lib.ctx_param_count(None) == _lib.CTX_E_INVALID
+    assert built_lib.ctx_sync(None) == _lib.CTX_E_INVALID
+    assert built_lib.ctx_dev_adam(None, 1e-4) == _lib.CTX_E_INVALID
+    built_lib.ctx_destroy(None)   # no-op
+
+
+def test_product_package_never_imports_the_oracle(repo_root):
+    pkg = os.path.join(repo_root, "imitation_from_observation_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "oracle" not in txt.replace("checker", ""), f"{f} mentions the oracle"

@@ -1,0 +1,57 @@
+"""The committed golden vectors (tests/golden/*.npz) against the oracle: guards the fixtures against
+RNG / oracle drift.  (The GPU tests compare the HIP path with the same files.)"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ctx_oracle as o
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load_case(path):
+    z = np.load(path)
+    H, W, C, d, F = (int(v) for v in z["cfg"])
+    cfg = o.SkipNewConfig(H=H, W=W, C=C, df_dim=d, gf_dim=d, featsize=F)
+    p = o.init_params(cfg, int(z["pseed"]), np.float64, stddev=float(z["stddev"]))
+    brng = np.random.default_rng(int(z["pseed"]) + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * float(z["stddev"])
+    return z, cfg, p
+
+
+def digest(a):
+    a = np.asarray(a, np.float64).reshape(-1)
+    return np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())])
+
+
+def test_fixtures_exist():
+    assert len(GOLD) >= 3
+
+
+@pytest.mark.parametrize("path", [g for g in GOLD if "d32" in g], ids=os.path.basename)
+def test_oracle_reproduces_golden(path):
+    z, cfg, p = load_case(path)
+    np.testing.assert_allclose(digest(o.flatten(p, cfg)), z["param_digest"], rtol=1e-12)
+    src, ctx, tgt = (o.preprocess_u8(z[k]).astype(np.float64) for k in ("src_u8", "ctx_u8", "tgt_u8"))
+    res, c = o.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        np.testing.assert_allclose(res[k], z[k], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([res["loss"], res["simloss"], res["recon1"], res["recon2"]], z["scalars"], rtol=1e-12)
+    g = o.backward(p, c, cfg)
+    for i, (n, _) in enumerate(o.param_specs(cfg)):
+        np.testing.assert_allclose(digest(g[n]), z["grad_digest"][i], rtol=1e-9, atol=1e-12)
+
+
+def test_oracle_f32_is_within_budget_of_golden_f64():
+    """The float32 oracle (the CPU baseline) vs the float64 fixture: sets the scale of fp32 noise the
+    1e-3 parity budget has to absorb (expect ~1e-6)."""
+    z, cfg, p = load_case([g for g in GOLD if "32x32" in g][0])
+    p32 = {k: v.astype(np.float32) for k, v in p.items()}
+    src, ctx, tgt = (o.preprocess_u8(z[k]) for k in ("src_u8", "ctx_u8", "tgt_u8"))
+    res, _ = o.forward(p32, src, ctx, tgt, cfg)
+    assert np.abs(res["out"] - z["out"]).max() <= 1e-4 * np.abs(z["out"]).max()
+    assert abs(res["loss"] - z["scalars"][0]) <= 1e-5 * z["scalars"][0]
