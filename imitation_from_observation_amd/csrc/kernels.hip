@@ -68,10 +68,14 @@ void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out,
 
 // ------------------------------------------------------------------------------------------------
 // uint8 frames -> f32 in [-1,1]: convert_image_dtype (x * (1/255)), - 0.5, * 2.0 as three separately
-// rounded f32 ops (rllab/sampler/base.py:116-119).  __f*_rn keeps hipcc from contracting them.
+// rounded f32 ops (rllab/sampler/base.py:116-119).  hipcc contracts a*b-c into an fma by default
+// (-ffp-contract=fast), which is 1 ulp off TF's three separate ops: contraction is switched off here.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float prep_u8(uint8_t x) {
-    return __fmul_rn(__fsub_rn(__fmul_rn((float)x, 1.0f / 255.0f), 0.5f), 2.0f);
+#pragma clang fp contract(off)
+    const float scaled = (float)x * (1.0f / 255.0f);
+    const float centred = scaled - 0.5f;
+    return centred * 2.0f;
 }
 
 __global__ __launch_bounds__(NTHREADS) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,

@@ -35,6 +35,7 @@ class HipEngine:
         n = Translator.arena_floats(H, W, df_dim, featsize)
         self.arena = torch.zeros(n, device=self.dev, dtype=torch.float32)
         self.stride = n // 4
+        torch.cuda.synchronize(self.dev)      # the zero-fill ran on torch's default stream
         # a dedicated torch stream (the legacy default stream has handle 0 = "make your own" in the C ABI)
         self.stream = torch.cuda.Stream(self.dev)
         self.translator = Translator(H, W, df_dim, featsize, max_batch, device=device,
