@@ -73,6 +73,7 @@ struct ctx_handle {
     float *dout = nullptr, *dE[4] = {}, *dSk[4] = {}, *dDz = nullptr, *dsim2 = nullptr;
     float *dth0 = nullptr, *dcz = nullptr, *dS[5] = {}, *dC[5] = {};
     float *scratch = nullptr, *slab = nullptr, *scalars = nullptr;
+    float* zeros = nullptr;   // 256 B of zeros for the branch-free loaders
     float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
     int64_t slab_floats = 0;
 
@@ -257,6 +258,8 @@ int alloc_buffers(ctx_handle* h) {
     h->slab_floats = 32ll << 20;
     TRY(dev_alloc(h, &h->slab, h->slab_floats));
     TRY(dev_alloc(h, &h->scalars, 4));
+    TRY(dev_alloc(h, &h->zeros, 64));
+    if (hipMemset(h->zeros, 0, 64 * sizeof(float)) != hipSuccess) return fail(h, CTX_E_DEVICE, "hipMemset(zeros)");
     return CTX_OK;
 }
 
@@ -276,8 +279,9 @@ const char* const K_COLSUM = "colsum";
 const char* const K_EW = "elementwise";
 
 // ---- layer launch helpers -------------------------------------------------------------------------
-NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K}; }
-KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC}; }
+thread_local const float* g_zeros = nullptr;   // 256 B of device zeros: where the loaders send out-of-range lanes (set per call)
+NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K, g_zeros}; }
+KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC, g_zeros}; }
 
 // y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
@@ -286,8 +290,8 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
-    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{x, hb, wb, hs, ws, R}, NmC3Weights{w, cb}, ep, R, cb, ws_of(h));
-    else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
+    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{x, hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
+    else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
 
 // y = act(x W + b), x possibly [x0 | x1] along K
@@ -362,6 +366,7 @@ enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
 // TRANSLATE: only what translated_z / out depend on (src encoder, ctx encoder, translate, decoder
 // pass 1) -- the subgraph TF would run for base.py:216-218.  ENCODE: `conv` encoder on src only.
 void forward(ctx_handle* h, int B, Mode mode) {
+    g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
     const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
@@ -371,7 +376,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
     if (mode == MODE_ENCODE) return;
     encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
     // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
-    KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC};
+    KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC, g_zeros};
     fc_layer(h, "translate/trans_h0", tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
     fc_layer(h, "translate/trans_z", km(h->th0, F, B, F), B, F, h->Wp("translate/trans_z/Matrix"), h->Wp("translate/trans_z/bias"), F, 0, h->Z);
     // decoder (arm_shaping.py:1321-1330, :1334-1343)
@@ -392,13 +397,13 @@ void forward(ctx_handle* h, int B, Mode mode) {
             ProfScope ps(h, nm_ + " fwd", K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R},
-                      KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC}, ep, R, ca, ws_of(h));
+            convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
+                      KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
             dec = h->e[k];
         } else {
             const int R = nd * hs * ws;
             { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl);
-              convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC}, w, c1 + c2, h->P3, R, ws_of(h)); }
+              convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
             { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
               convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
         }
@@ -408,6 +413,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
 // d loss / d params into the grad arena (what AdamOptimizer.minimize differentiates,
 // scripts/train_script.py:128).  Every gradient tensor is written exactly once.
 void backward(ctx_handle* h, int B, int sim_batch) {
+    g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
     hipStream_t s = h->stream;
@@ -432,7 +438,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
         bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
         const double fl = 2.0 * R * 25 * cb * ca;
-        NmWgradSmall small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, R};
+        NmWgradSmall small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
         Epi eg;
         eg.out1 = h->Gp((nm_ + "/w").c_str()); eg.ld1 = cb;
         // input gradient = SAME stride-2 conv of dy with the same filter read as [5,5,ca,cb]; cols < c1
@@ -441,12 +447,12 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
         if (ca == 3) {
-            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, hs, wsm, R}, small, eg, cb, ws); }
-            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R}, NmC3Weights{w, cb}, ed, R, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws); }
         } else {
-            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
-              conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
+              conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
         }
         dy = d_dec;
     }
@@ -464,7 +470,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         Epi e1;
         e1.out1 = h->dth0; e1.ld1 = F; e1.mask = h->th0; e1.ldm = F;
         fc_dx(h, "translate/trans_z", h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
-        NmPlain tcat{src_z, F, h->cz, F, F, 2 * F, B};
+        NmPlain tcat{src_z, F, h->cz, F, F, 2 * F, B, g_zeros};
         fc_dw(h, "translate/trans_h0", tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
         Epi e2;   // d concat: cols < F -> d src_z (row block 2 of dZ), cols >= F -> d ctx_z
         e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;
@@ -491,15 +497,15 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             const std::string ln = scn + "/h" + std::to_string(k) + "_conv";
             const double fl = 2.0 * R * 25 * ca * cb;
             bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
-            NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, R};
+            NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
             Epi eg;
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
             if (k == 0) {
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
-                conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, hs, wsm, R}, small, eg, cb, ws);
+                conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws);
                 break;   // no gradient w.r.t. the frame
             }
-            { ProfScope ps(h, ln + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, hs, wsm, R}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, ln + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
             // input gradient = conv2d_transpose of dA[k] with the same filter read as [5,5,ca,cb]
             Epi ed;
             ed.out1 = dA[k - 1]; ed.ld1 = ca; ed.mask = act[k - 1]; ed.ldm = ca;
@@ -508,7 +514,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
             ProfScope ps(h, ln + " dx", K_CONVT, fl);
-            convt_fwd(s, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R}, KmConvTWeights{sc.w[k], ca, cb, cb / KC},
+            convt_fwd(s, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
                       ed, R, ca, ws);
         }
     };

@@ -2,7 +2,9 @@
 // The same two kernels also compute each other's input gradient.
 #include "gemm_launch.h"
 namespace ctx {
-void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b, Epi ep, int M, int N, SplitWs ws) {
+void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, int M, int N, SplitWs ws) {
+    NmPlain b = b_;
+    b.seglen = a.cps * KC;     // filter rows in KmConvGather's K order
     launch_igemm(s, a, b, ep, M, N, 1, 25 * a.cps, ws);
 }
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
@@ -12,7 +14,7 @@ void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, E
 }
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws) {
     // B[k][n] = w[ky,kx,c,k] with n = (ky*5+kx)*3+c: the filter itself, rows n contiguous in k
-    KmPlain b{w, cb, nullptr, 0, cb, 75, cb / KC};
+    KmPlain b{w, cb, nullptr, 0, cb, 75, cb / KC, a.zeros};
     Epi ep;
     ep.out1 = P; ep.ld1 = P3_LD;
     launch_igemm(s, a, b, ep, M, 75, 1, 0, ws);

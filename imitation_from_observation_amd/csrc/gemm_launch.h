@@ -1,5 +1,7 @@
 // gemm_launch.h -- tile-shape dispatch and split-K policy for igemm_kernel (included by gemm_*.hip)
 #pragma once
+#include <cstdlib>
+
 #include "launch.h"
 
 namespace ctx {
@@ -9,9 +11,16 @@ void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int ns
 template <class LA, class LB, int MI, int NI>
 static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
     constexpr int TM = 64 * MI, TN = 64 * NI;
-    constexpr size_t lds = (size_t)(Tile<LA::KM, TM>::FLOATS + Tile<LB::KM, TN>::FLOATS) * sizeof(float);
-    dim3 grid((M + TM - 1) / TM, (N + TN - 1) / TN, nprob * nsplit);
-    hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI>), grid, dim3(NTHREADS), lds, s, a, b, ep, M, N, nprob, nsplit);
+    // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
+    constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM>::FLOATS + Tile<LB::KM, TN>::FLOATS) * sizeof(float);
+    static bool raised = false;
+    if (lds > 65536 && !raised) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<LA, LB, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
+    dim3 grid((unsigned)((int64_t)gm * gn * nprob * nsplit));
+    hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI>), grid, dim3(NTHREADS), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 
 // Blocks wanted before the K loop is split: 256 CUs x ~3 resident blocks.

@@ -12,7 +12,19 @@
 // Nothing is materialised in HBM: each block gathers 128-B channel runs of the pixels it needs
 // straight into LDS (coalesced), and the 25-tap reuse comes from L2.
 //
-// Block = 256 threads = 4 waves (2 x 2), block tile (64*MI) x (64*NI), K staged KC = 32 at a time.
+// Block = 256 threads = 4 waves (2 x 2), block tile (64*MI) x (64*NI), K staged KC = 32 at a time
+// through a double-buffered LDS ring with ONE barrier per chunk.  Measured anatomy on MI355X
+// (tools/mfma_ablate.hip): the MFMA stream alone runs at the 152 TF/s pipe peak (2.32 GHz); what
+// costs is anything that sits BETWEEN a barrier and the first MFMA.  Therefore
+//   * loaders are branch-free -- out-of-range lanes (SAME padding, ragged edges) read a zero page, so
+//     the whole chunk body is one basic block the scheduler can interleave;
+//   * per-row state (base pointer, 25-bit tap-validity mask) is hoisted out of the K loop; per chunk
+//     only a wave-uniform offset is added;
+//   * the global loads of chunk c+2 and the LDS stores of chunk c+1 are issued in the gaps between
+//     the MFMA groups of chunk c (two register sets: 1.5 chunks between a load and its first use).
+// What did NOT help (measured, kept out): XCD-contiguous / n-tile-fastest block orders (-8..-20 %),
+// pinning the schedule with sched_barrier (-2 %).  What remains (72 % of the pipe peak at the measured
+// clock) tracks L2-miss traffic per FLOP, not latency: see DESIGN.md section 6.
 // LDS tile formats (both conflict-free, guide section 2 / Guideline 4):
 //   KM ("k-minor"): tile[row][KC+4]; a lane reads 4 consecutive k with one ds_read_b128 (row
 //       stride 36 dwords spreads a 16-lane group over all 64 banks) and feeds 4 MFMAs.
@@ -32,8 +44,45 @@ constexpr int LDK = KC + 4;
 constexpr int NTHREADS = 256;
 constexpr float LEAK = 0.2f;  // arm_shaping.py:18
 
+// (n, i, j) of a flat pixel index; shifts when the grid is a power of two (the 64x64 production
+// size), integer division otherwise.  sh < 0 means "not a power of two".
+struct PixDiv {
+    int ws, hs, ws_sh, hs_sh;
+    __device__ __forceinline__ void split(int p, int& n, int& i, int& j) const {
+        if (ws_sh >= 0 && hs_sh >= 0) {
+            j = p & (ws - 1);
+            const int t = p >> ws_sh;
+            i = t & (hs - 1);
+            n = t >> hs_sh;
+        } else {
+            j = p % ws;
+            const int t = p / ws;
+            i = t % hs;
+            n = t / hs;
+        }
+    }
+};
+inline PixDiv make_pixdiv(int hs, int ws) {
+    auto sh = [](int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; };
+    return PixDiv{ws, hs, sh(ws), sh(hs)};
+}
+
+// chunk -> (tap segment, channel-slice index) for "slice outer, taps inner" K order; ntap in {4,6,9,25}
+// is matched to a literal so the division is a multiply-shift on the scalar unit
+__device__ __forceinline__ void tap_slice(int chunk, int ntap, int& seg, int& slice) {
+    switch (ntap) {
+        case 4: slice = chunk >> 2; break;
+        case 6: slice = chunk / 6; break;
+        case 9: slice = chunk / 9; break;
+        default: slice = chunk / 25; break;
+    }
+    seg = chunk - slice * ntap;
+}
+
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// branch-free guarded load: `zeros` is >= 16 bytes of device zeros
+__device__ __forceinline__ float4 ldg4_or0(const float* p, bool ok, const float* zeros) { return ldg4(ok ? p : zeros); }
 
 // ------------------------------------------------------------------------------------------------
 // Epilogue: what happens to D.  One struct serves forward (bias + lrelu), backward (skip-gradient
@@ -89,9 +138,10 @@ __device__ __forceinline__ void epi_store(const Epi& e, int prob, int64_t pix, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Loaders.  KM loaders: prep(prob,row,ctx) once, then load(ctx,prob,chunk,k4) -> 4 consecutive k.
-//           NM loaders: load(prob,chunk,kk,r4) -> rows r4..r4+3 at k = chunk*32+kk.
-// All return zeros outside the virtual matrix (SAME padding, ragged M/N/K).
+// Loaders.  KM loaders: prep(prob,row,ctx) once per tile row, then load(ctx,prob,chunk,k4) -> 4
+//           consecutive k.  NM loaders: load(prob,chunk,kk,r4) -> rows r4..r4+3 at k = chunk*32+kk.
+// All are branch-free and return zeros outside the virtual matrix (SAME padding, ragged M/N/K) by
+// redirecting the load to `zeros`.
 // ------------------------------------------------------------------------------------------------
 
 // Plain row-major matrix V[row][k], optionally split along k into two buffers (the translate MLP's
@@ -100,16 +150,20 @@ struct KmPlain {
     static constexpr bool KM = true;
     const float* p0; int64_t ld0;
     const float* p1; int64_t ld1;
-    int ksplit;      // k < ksplit -> p0, else p1[k - ksplit]
+    int ksplit;      // k < ksplit -> p0, else p1[k - ksplit]; a multiple of KC
     int R;           // valid rows
     int nchunks;
-    struct Ctx { int64_t row; bool ok; };
+    const float* zeros;
+    struct Ctx { const float* r0; const float* r1; bool ok; };
     __device__ int nchunks_of(int) const { return nchunks; }
-    __device__ void prep(int, int row, Ctx& c) const { c.row = row; c.ok = row < R; }
+    __device__ void prep(int, int row, Ctx& c) const {
+        c.ok = row < R;
+        c.r0 = p0 + (int64_t)row * ld0;
+        c.r1 = p1 + (int64_t)row * ld1 - ksplit;
+    }
     __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        if (!c.ok) return zero4();
         const int k = chunk * KC + k4;
-        return k < ksplit ? ldg4(p0 + c.row * ld0 + k) : ldg4(p1 + c.row * ld1 + (k - ksplit));
+        return ldg4_or0((chunk * KC < ksplit ? c.r0 : c.r1) + k, c.ok, zeros);
     }
 };
 
@@ -121,19 +175,30 @@ struct KmConvGather {
     int hb, wb, hs, ws;            // input (big) and output (small) grids
     int cps;                       // chunks per tap = cin / 32
     int R;                         // imgs * hs * ws
-    struct Ctx { int64_t img_base; int i2, j2; bool ok; };
+    const float* zeros;
+    struct Ctx { const float* base; unsigned mask; };   // base -> input pixel (2i-1, 2j-1); mask bit = tap valid
     __device__ int nchunks_of(int) const { return 25 * cps; }
     __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        c.img_base = (int64_t)n * hb * wb; c.i2 = 2 * i - 1; c.j2 = 2 * j - 1;
+        const int i2 = 2 * i - 1, j2 = 2 * j - 1;
+        c.base = x + (((int64_t)n * hb + i2) * wb + j2) * ldx;
+        unsigned m = 0;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx)
+                if ((unsigned)(i2 + ky) < (unsigned)hb && (unsigned)(j2 + kx) < (unsigned)wb) m |= 1u << (ky * 5 + kx);
+        c.mask = row < R ? m : 0u;
     }
     __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        const int seg = chunk / cps, kc = (chunk - seg * cps) * KC;
+        // K order: 32-channel slice outer, the 25 taps inner -- a block re-reads one slice of its input
+        // halo (L2-resident) 25 times before moving to the next slice
+        int seg, slice;
+        tap_slice(chunk, 25, seg, slice);                                 // wave-uniform
+        const int kc = slice * KC;
         const int ky = seg / 5, kx = seg - ky * 5;
-        const int y = c.i2 + ky, xx = c.j2 + kx;
-        if (!c.ok || (unsigned)y >= (unsigned)hb || (unsigned)xx >= (unsigned)wb) return zero4();
-        return ldg4(x + (c.img_base + (int64_t)y * wb + xx) * ldx + kc + k4);
+        const int64_t off = (int64_t)(ky * wb + kx) * ldx + kc;           // wave-uniform
+        return ldg4_or0(c.base + off + k4, (c.mask >> seg) & 1u, zeros);
     }
 };
 
@@ -143,25 +208,37 @@ struct KmConvGather {
 // passes, so its image index is img % nmod2 (arm_shaping.py:1323 and :1336 use the same tgtctx_h*).
 struct KmConvTGather {
     static constexpr bool KM = true;
-    const float* s1; int64_t ld1; int c1;
+    const float* s1; int64_t ld1; int c1;   // c1 a multiple of KC
     const float* s2; int64_t ld2; int nmod2;
     int hs, ws;
     int cps;                       // (c1 + c2) / 32
     int R;
-    struct Ctx { int n, i, j; bool ok; };
+    const float* zeros;
+    struct Ctx { const float* b1; const float* b2; unsigned mask; };   // b* -> input pixel (i'+py, j'+px)
     __device__ int nchunks_of(int prob) const { return (2 + (prob >> 1)) * (2 + (prob & 1)) * cps; }
-    __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
-        c.j = row % ws; const int t = row / ws; c.i = t % hs; c.n = t / hs;
+    __device__ void prep(int prob, int row, Ctx& c) const {
+        const int py = prob >> 1, px = prob & 1;
+        const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
+        const int64_t pix = (int64_t)(i + py) * ws + (j + px);
+        c.b1 = s1 + ((int64_t)n * hs * ws + pix) * ld1;
+        c.b2 = s2 + ((int64_t)(n % nmod2) * hs * ws + pix) * ld2 - c1;
+        unsigned m = 0;
+#pragma unroll
+        for (int sy = 0; sy < 3; ++sy)
+#pragma unroll
+            for (int sx = 0; sx < 3; ++sx)
+                if ((unsigned)(i + py - sy) < (unsigned)hs && (unsigned)(j + px - sx) < (unsigned)ws) m |= 1u << (sy * 3 + sx);
+        c.mask = row < R ? m : 0u;
     }
     __device__ float4 load(const Ctx& c, int prob, int chunk, int k4) const {
-        const int py = prob >> 1, px = prob & 1, ntx = 2 + px;
-        const int seg = chunk / cps, k = (chunk - seg * cps) * KC + k4;
-        const int sy = seg / ntx, sx = seg - sy * ntx;
-        const int i = c.i + py - sy, j = c.j + px - sx;
-        if (!c.ok || (unsigned)i >= (unsigned)hs || (unsigned)j >= (unsigned)ws) return zero4();
-        if (k < c1) return ldg4(s1 + (((int64_t)c.n * hs + i) * ws + j) * ld1 + k);
-        return ldg4(s2 + (((int64_t)(c.n % nmod2) * hs + i) * ws + j) * ld2 + (k - c1));
+        const int ntx = 2 + (prob & 1), ntap = (2 + (prob >> 1)) * ntx;
+        int seg, slice;
+        tap_slice(chunk, ntap, seg, slice);                               // wave-uniform; slice outer, taps inner
+        const int kc = slice * KC;
+        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
+        const int poff = sy * ws + sx;                                    // pixels back from (i'+py, j'+px)
+        const float* p = kc < c1 ? c.b1 - (int64_t)poff * ld1 : c.b2 - (int64_t)poff * ld2;
+        return ldg4_or0(p + kc + k4, (c.mask >> (sy * 3 + sx)) & 1u, zeros);
     }
 };
 
@@ -170,48 +247,18 @@ struct KmConvTWeights {
     static constexpr bool KM = true;
     const float* w; int ca, cb;    // cb = c1 + c2
     int cps;
-    struct Ctx { int row; bool ok; };
+    const float* zeros;
+    struct Ctx { const float* rowp; bool ok; };
     __device__ int nchunks_of(int) const { return 0; }
-    __device__ void prep(int, int row, Ctx& c) const { c.row = row; c.ok = row < ca; }
+    __device__ void prep(int, int row, Ctx& c) const { c.ok = row < ca; c.rowp = w + (int64_t)row * cb; }
     __device__ float4 load(const Ctx& c, int prob, int chunk, int k4) const {
-        if (!c.ok) return zero4();
-        const int py = prob >> 1, px = prob & 1, ntx = 2 + px;
-        const int seg = chunk / cps, k = (chunk - seg * cps) * KC + k4;
-        const int sy = seg / ntx, sx = seg - sy * ntx;
+        const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
+        int seg, slice;
+        tap_slice(chunk, ntap, seg, slice);                               // same K order as KmConvTGather
+        const int kc = slice * KC;
+        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
         const int ky = 1 - py + 2 * sy, kx = 1 - px + 2 * sx;
-        return ldg4(w + ((int64_t)(ky * 5 + kx) * ca + c.row) * cb + k);
-    }
-};
-
-// conv2d forward operand when cin == 3 (the frame itself, or the decoder's output gradient): for a
-// fixed ky the 5 taps x 3 channels of a row are 15 CONTIGUOUS floats starting at pixel (.., 2j-1).
-// A chunk holds two ky segments of 16 (15 + one zero); 3 chunks cover ky = 0..4.
-struct KmC3Gather {
-    static constexpr bool KM = true;
-    const float* x;
-    int hb, wb, hs, ws;
-    int R;
-    struct Ctx { int64_t img_base; int i2, j2; bool ok; };
-    __device__ int nchunks_of(int) const { return 3; }
-    __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
-        const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        c.img_base = (int64_t)n * hb * wb; c.i2 = 2 * i - 1; c.j2 = 2 * j - 1;
-    }
-    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        const int ky = 2 * chunk + (k4 >> 4);
-        const int y = c.i2 + ky;
-        if (c.ok && ky < 5 && (unsigned)y < (unsigned)hb) {
-            const float* rowp = x + (c.img_base + (int64_t)y * wb) * 3;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int el = (k4 & 15) + u;       // (kx, ch) = (el / 3, el % 3)
-                const int xx = c.j2 + el / 3;
-                if (el < 15 && (unsigned)xx < (unsigned)wb) v[u] = rowp[(int64_t)c.j2 * 3 + el];
-            }
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
+        return ldg4_or0(c.rowp + (int64_t)(ky * 5 + kx) * ca * cb + kc + k4, c.ok, zeros);
     }
 };
 
@@ -224,18 +271,50 @@ struct KmCat2 {
     int hsws;        // pixels per image
     int R;           // pixels
     int cps;         // (c1 + c2) / 32
-    struct Ctx { int64_t p1, p2; bool ok; };
+    const float* zeros;
+    struct Ctx { const float* p1; const float* p2; bool ok; };
     __device__ int nchunks_of(int) const { return cps; }
     __device__ void prep(int, int row, Ctx& c) const {
         c.ok = row < R;
         const int n = row / hsws, rem = row - n * hsws;
-        c.p1 = (int64_t)row * ld1;
-        c.p2 = ((int64_t)(n % nmod2) * hsws + rem) * ld2;
+        c.p1 = s1 + (int64_t)row * ld1;
+        c.p2 = s2 + ((int64_t)(n % nmod2) * hsws + rem) * ld2 - c1;
     }
     __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        if (!c.ok) return zero4();
         const int k = chunk * KC + k4;
-        return k < c1 ? ldg4(s1 + c.p1 + k) : ldg4(s2 + c.p2 + (k - c1));
+        return ldg4_or0((chunk * KC < c1 ? c.p1 : c.p2) + k, c.ok, zeros);
+    }
+};
+
+// conv2d forward operand when cin == 3 (the frame itself, or the decoder's output gradient): for a
+// fixed ky the 5 taps x 3 channels of a row are 15 CONTIGUOUS floats starting at pixel (.., 2j-1).
+// A chunk holds two ky segments of 16 (15 + one zero); 3 chunks cover ky = 0..4.
+struct KmC3Gather {
+    static constexpr bool KM = true;
+    const float* x;
+    int hb, wb, hs, ws;
+    int R;
+    const float* zeros;
+    struct Ctx { const float* base; int i2, j2; bool ok; };   // base -> element (2i-1, 2j-1, 0)
+    __device__ int nchunks_of(int) const { return 3; }
+    __device__ void prep(int, int row, Ctx& c) const {
+        c.ok = row < R;
+        const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
+        c.i2 = 2 * i - 1; c.j2 = 2 * j - 1;
+        c.base = x + (((int64_t)n * hb + c.i2) * wb + c.j2) * 3;
+    }
+    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
+        const int ky = 2 * chunk + (k4 >> 4);
+        const bool rowok = c.ok && ky < 5 && (unsigned)(c.i2 + ky) < (unsigned)hb;
+        const float* rowp = c.base + (int64_t)ky * wb * 3;
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int el = (k4 & 15) + u;        // (kx, ch) = (el / 3, el % 3)
+            const bool ok = rowok && el < 15 && (unsigned)(c.j2 + el / 3) < (unsigned)wb;
+            v[u] = *(ok ? rowp + el : zeros);
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
     }
 };
 
@@ -247,11 +326,19 @@ struct NmPlain {
     int rsplit;      // r < rsplit -> p0, else p1[r - rsplit]
     int R;           // valid r
     int K;           // valid k
+    const float* zeros;
+    int seglen = 0;  // > 0: K = 25 tap segments of seglen rows, chunk order (slice outer, tap inner) to match
+                     //      KmConvGather -- the conv filter [25][cin][cout]
     __device__ int nchunks_of(int) const { return (K + KC - 1) / KC; }
     __device__ float4 load(int, int chunk, int kk, int r4) const {
-        const int k = chunk * KC + kk;
-        if (k >= K || r4 >= R) return zero4();
-        return r4 < rsplit ? ldg4(p0 + (int64_t)k * ld0 + r4) : ldg4(p1 + (int64_t)k * ld1 + (r4 - rsplit));
+        int k = chunk * KC + kk;
+        if (seglen) {
+            int seg, slice;
+            tap_slice(chunk, 25, seg, slice);
+            k = seg * seglen + slice * KC + kk;
+        }
+        const float* p = r4 < rsplit ? p0 + (int64_t)k * ld0 + r4 : p1 + (int64_t)k * ld1 + (r4 - rsplit);
+        return ldg4_or0(p, k < K && r4 < R, zeros);
     }
 };
 
@@ -259,10 +346,10 @@ struct NmPlain {
 struct NmC3Weights {
     static constexpr bool KM = false;
     const float* w; int cb;
+    const float* zeros;
     __device__ float4 load(int, int chunk, int kk, int r4) const {
         const int ky = 2 * chunk + (kk >> 4), el = kk & 15;
-        if (ky >= 5 || el == 15 || r4 >= cb) return zero4();
-        return ldg4(w + (int64_t)(ky * 15 + el) * cb + r4);
+        return ldg4_or0(w + (int64_t)(ky * 15 + el) * cb + r4, ky < 5 && el < 15 && r4 < cb, zeros);
     }
 };
 
@@ -271,17 +358,19 @@ struct NmC3Weights {
 struct NmWgradBig {
     static constexpr bool KM = false;
     const float* big; int64_t ldb; int ca;
-    int hb, wb, hs, ws;
+    int hb, wb;
+    PixDiv pd;
     int npix;        // imgs * hs * ws
+    const float* zeros;
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
     __device__ float4 load(int prob, int chunk, int kk, int r4) const {
         const int p = chunk * KC + kk;
-        if (p >= npix || r4 >= ca) return zero4();
         const int ky = prob / 5, kx = prob - ky * 5;
-        const int j = p % ws, t = p / ws, i = t % hs, n = t / hs;
+        int n, i, j;
+        pd.split(p, n, i, j);
         const int y = 2 * i + ky - 1, xx = 2 * j + kx - 1;
-        if ((unsigned)y >= (unsigned)hb || (unsigned)xx >= (unsigned)wb) return zero4();
-        return ldg4(big + (((int64_t)n * hb + y) * wb + xx) * ldb + r4);
+        const bool ok = p < npix && r4 < ca && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb;
+        return ldg4_or0(big + (((int64_t)n * hb + y) * wb + xx) * ldb + r4, ok, zeros);
     }
 };
 
@@ -293,13 +382,14 @@ struct NmWgradSmall {
     const float* s2; int64_t ld2; int nmod2;
     int cb;          // c1 + c2
     int hsws;        // pixels per image
+    int hsws_sh;     // log2(hsws) or -1
     int npix;
+    const float* zeros;
     __device__ float4 load(int, int chunk, int kk, int r4) const {
         const int p = chunk * KC + kk;
-        if (p >= npix || r4 >= cb) return zero4();
-        if (r4 < c1) return ldg4(s1 + (int64_t)p * ld1 + r4);
-        const int n = p / hsws, rem = p - n * hsws;
-        return ldg4(s2 + ((int64_t)(n % nmod2) * hsws + rem) * ld2 + (r4 - c1));
+        const int n = hsws_sh >= 0 ? p >> hsws_sh : p / hsws, rem = p - n * hsws;
+        const float* q = r4 < c1 ? s1 + (int64_t)p * ld1 + r4 : s2 + ((int64_t)(n % nmod2) * hsws + rem) * ld2 + (r4 - c1);
+        return ldg4_or0(q, p < npix && r4 < cb, zeros);
     }
 };
 
@@ -307,25 +397,25 @@ struct NmWgradSmall {
 struct NmC3WgradBig {
     static constexpr bool KM = false;
     const float* big;
-    int hb, wb, hs, ws;
+    int hb, wb;
+    PixDiv pd;
     int npix;
+    const float* zeros;
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
     __device__ float4 load(int, int chunk, int kk, int r4) const {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
         const int p = chunk * KC + kk;
         const int ky = r4 >> 4;
-        if (p < npix && ky < 5) {
-            const int j = p % ws, t = p / ws, i = t % hs, n = t / hs;
-            const int y = 2 * i + ky - 1, j2 = 2 * j - 1;
-            if ((unsigned)y < (unsigned)hb) {
-                const float* rowp = big + (((int64_t)n * hb + y) * wb) * 3;
+        int n, i, j;
+        pd.split(p, n, i, j);
+        const int y = 2 * i + ky - 1, j2 = 2 * j - 1;
+        const bool rowok = p < npix && ky < 5 && (unsigned)y < (unsigned)hb;
+        const float* rowp = big + ((((int64_t)n * hb + y) * wb) + j2) * 3;
+        float v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int el = (r4 & 15) + u;
-                    const int xx = j2 + el / 3;
-                    if (el < 15 && (unsigned)xx < (unsigned)wb) v[u] = rowp[(int64_t)j2 * 3 + el];
-                }
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int el = (r4 & 15) + u;
+            const bool ok = rowok && el < 15 && (unsigned)(j2 + el / 3) < (unsigned)wb;
+            v[u] = *(ok ? rowp + el : zeros);
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -359,6 +449,7 @@ struct Tile {
     }
 };
 
+// per-thread view of a loader: which float4 of a chunk this thread fetches in pass p
 template <class L, int TR, bool KMF = L::KM>
 struct Fetch;
 template <class L, int TR>
@@ -368,38 +459,45 @@ struct Fetch<L, TR, true> {
 #pragma unroll
         for (int p = 0; p < TR / 32; ++p) l.prep(prob, row0 + Tile<true, TR>::km_row(tid, p), c[p]);
     }
-    __device__ void load(const L& l, int prob, int, int chunk, int tid, float4 (&r)[TR / 32]) const {
-#pragma unroll
-        for (int p = 0; p < TR / 32; ++p) r[p] = l.load(c[p], prob, chunk, Tile<true, TR>::km_k4(tid));
+    __device__ float4 load1(const L& l, int prob, int, int chunk, int tid, int p) const {
+        return l.load(c[p], prob, chunk, Tile<true, TR>::km_k4(tid));
     }
 };
 template <class L, int TR>
 struct Fetch<L, TR, false> {
     __device__ void init(const L&, int, int, int) {}
-    __device__ void load(const L& l, int prob, int row0, int chunk, int tid, float4 (&r)[TR / 32]) const {
-#pragma unroll
-        for (int p = 0; p < TR / 32; ++p)
-            r[p] = l.load(prob, chunk, Tile<false, TR>::nm_kk(tid, p), row0 + Tile<false, TR>::nm_r4(tid));
+    __device__ float4 load1(const L& l, int prob, int row0, int chunk, int tid, int p) const {
+        return l.load(prob, chunk, Tile<false, TR>::nm_kk(tid, p), row0 + Tile<false, TR>::nm_r4(tid));
     }
 };
 
 // ------------------------------------------------------------------------------------------------
-// The kernel.  grid = (m tiles, n tiles, nprob * nsplit).
+// The kernel.  1-D grid of gm * gn * nprob * nsplit blocks.
 // ------------------------------------------------------------------------------------------------
+
 template <class LA, class LB, int MI, int NI>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB lb, const Epi ep, int M, int N,
-                                                         int nprob, int nsplit) {
+                                                         int nprob, int nsplit, int gm, int gn) {
     constexpr int TM = 64 * MI, TN = 64 * NI;
     using TA = Tile<LA::KM, TM>;
     using TB = Tile<LB::KM, TN>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;
-    float* sB = smem + TA::FLOATS;
+    constexpr int NA = TA::NPASS, NB = TB::NPASS;       // float4 per thread per chunk: 2..4 each
+    constexpr int STAGE = TA::FLOATS + TB::FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages of [A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
-    const int prob = blockIdx.z % nprob, split = blockIdx.z / nprob;
+
+    // 1-D grid, m-tile fastest, then n-tile, then problem, then K-split.  Problems go last-first: the
+    // (1,1) parity class of a transposed conv has 9 taps against 4 for (0,0), and the longest blocks
+    // must not form the tail.  (XCD-contiguous and n-tile-fastest orders were measured: -8..-20 %.)
+    int rest = blockIdx.x;
+    const int bx = rest % gm; rest /= gm;
+    const int by = rest % gn; rest /= gn;
+    const int prob = nprob - 1 - rest % nprob;
+    const int split = rest / nprob;
+    const int m0 = bx * TM, n0 = by * TN;
+
     const int nch = la.nchunks_of(prob);
     const int per = (nch + nsplit - 1) / nsplit;
     const int cb = split * per;
@@ -418,37 +516,67 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB l
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    float4 ra[TA::NPASS], rb[TB::NPASS];
     if (cb < ce) {
-        fa.load(la, prob, m0, cb, tid, ra);
-        fb.load(lb, prob, n0, cb, tid, rb);
-    }
-    for (int c = cb; c < ce; ++c) {
+        const int last = ce - 1;
+        // Two register sets: while chunk c is multiplied out of LDS stage c&1, set X (chunk c+1, loaded
+        // during chunk c-1) is stored to the other stage in the SECOND half of the MFMA stream and set Y
+        // is refilled with chunk c+2 in the FIRST half -- 1.5 chunks (>= 6000 cycles) between a load's
+        // issue and its first use, which covers an L2 miss to Infinity Cache / HBM.
+        float4 xa[NA], xb[NB], ya[NA], yb[NB];
+        auto clampc = [&](int c) { return c < last ? c : last; };   // redundant tail reloads are harmless
+        // prologue: chunk cb -> stage 0 ; chunk cb+1 -> set X
 #pragma unroll
-        for (int p = 0; p < TA::NPASS; ++p) TA::store(sA, tid, p, ra[p]);
+        for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, prob, m0, cb, tid, p);
 #pragma unroll
-        for (int p = 0; p < TB::NPASS; ++p) TB::store(sB, tid, p, rb[p]);
+        for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, prob, n0, cb, tid, p);
+#pragma unroll
+        for (int p = 0; p < NA; ++p) TA::store(smem, tid, p, xa[p]);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) TB::store(smem + TA::FLOATS, tid, p, xb[p]);
+#pragma unroll
+        for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, prob, m0, clampc(cb + 1), tid, p);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, prob, n0, clampc(cb + 1), tid, p);
         __syncthreads();
-        if (c + 1 < ce) {   // next chunk's HBM/L2 reads fly under this chunk's 64 MFMAs
-            fa.load(la, prob, m0, c + 1, tid, ra);
-            fb.load(lb, prob, n0, c + 1, tid, rb);
-        }
+
+        // one chunk: multiply stage `st`; slots 0..7 load chunk c+2 into (la_, lb_); slots 8..15 store
+        // (sa_, sb_) = chunk c+1 into the other stage
+        auto chunk = [&](int c, int st, float4 (&la_)[NA], float4 (&lb_)[NB], float4 (&sa_)[NA], float4 (&sb_)[NB]) {
+            const float* sA = smem + st * STAGE;
+            const float* sB = sA + TA::FLOATS;
+            float* nA = smem + (st ^ 1) * STAGE;
+            float* nB = nA + TA::FLOATS;
+            const int c2 = clampc(c + 2);
+            float a[2][MI][4], b[2][NI][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float a[MI][4], b[NI][4];
+            for (int mi = 0; mi < MI; ++mi) TA::frag(sA, wm * 32 * MI + mi * 32 + l31, 0, h, a[0][mi]);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) TA::frag(sA, wm * 32 * MI + mi * 32 + l31, q, h, a[mi]);
+            for (int ni = 0; ni < NI; ++ni) TB::frag(sB, wn * 32 * NI + ni * 32 + l31, 0, h, b[0][ni]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) TB::frag(sB, wn * 32 * NI + ni * 32 + l31, q, h, b[ni]);
+            for (int g = 0; g < 16; ++g) {
+                const int q = g >> 2, t = g & 3;
+                if (t == 0 && q < 3) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                    for (int mi = 0; mi < MI; ++mi) TA::frag(sA, wm * 32 * MI + mi * 32 + l31, q + 1, h, a[(q + 1) & 1][mi]);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) TB::frag(sB, wn * 32 * NI + ni * 32 + l31, q + 1, h, b[(q + 1) & 1][ni]);
+                }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][t], b[ni][t], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi][t], b[q & 1][ni][t], acc[mi][ni], 0, 0, 0);
+                if (g < NA) la_[g] = fa.load1(la, prob, m0, c2, tid, g);
+                else if (g < NA + NB) lb_[g - NA] = fb.load1(lb, prob, n0, c2, tid, g - NA);
+                else if (g >= 8 && g - 8 < NA) TA::store(nA, tid, g - 8, sa_[g - 8]);
+                else if (g >= 8 && g - 8 < NA + NB) TB::store(nB, tid, g - 8 - NA, sb_[g - 8 - NA]);
+            }
+            __syncthreads();
+        };
+        for (int c = cb; c < ce; c += 2) {
+            chunk(c, 0, ya, yb, xa, xb);
+            if (c + 1 < ce) chunk(c + 1, 1, xa, xb, ya, yb);
         }
-        __syncthreads();
     }
 
     // D layout (32x32 MFMA): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)

@@ -231,13 +231,23 @@ __global__ __launch_bounds__(NTHREADS) void colsum3_partial_kernel(const float* 
     if (threadIdx.x == 0) { part[blockIdx.x * 4 + 0] = r0; part[blockIdx.x * 4 + 1] = r1; part[blockIdx.x * 4 + 2] = r2; }
 }
 
+// stage 2: 32 columns x 8 slab lanes per block; lane sums in fixed order, then the 8 lanes in fixed order
 __global__ __launch_bounds__(NTHREADS) void colsum_final_kernel(const float* __restrict__ part, int nsl, int C, int ldp,
                                                                 float* __restrict__ out) {
-    const int c = blockIdx.x * NTHREADS + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float sh[8][32];
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float acc = 0.f;
-    for (int sl = 0; sl < nsl; ++sl) acc += part[(int64_t)sl * ldp + c];
-    out[c] = acc;
+    if (c < C)
+        for (int sl = ln; sl < nsl; sl += 8) acc += part[(int64_t)sl * ldp + c];
+    sh[ln][cl] = acc;
+    __syncthreads();
+    if (ln == 0 && c < C) {
+        float r = sh[0][cl];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r += sh[k][cl];
+        out[c] = r;
+    }
 }
 
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out) {
@@ -259,8 +269,7 @@ void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, 
     const int64_t rows_per = (rows + nsl - 1) / nsl;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((c4 + tpr - 1) / tpr, nsl), dim3(NTHREADS), 0, s, x, rows, C, tpr, rows_per,
                        scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + NTHREADS - 1) / NTHREADS), dim3(NTHREADS), 0, s,
-                       (const float*)scratch, nsl, C, C, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 31) / 32), dim3(NTHREADS), 0, s, (const float*)scratch, nsl, C, C, out);
 }
 
 // ------------------------------------------------------------------------------------------------
