@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=5)
+    ap.add_argument("--host-buffers", action="store_true",
+                    help="also time ctx_train_step on host (numpy) frames: the PCIe-inclusive rate quoted in DESIGN.md")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +139,13 @@ def main():
                 for e in ents:
                     tf = e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else 0
                     f.write(f"{e['name']:34s} {e['kernel']:34s} {e['ms']:9.4f} ms {tf:8.2f} TF/s\n")
+        if args.host_buffers:
+            hs, hc, ht = (x.cpu().numpy() for x in (src, ctx, tgt))
+            tr.train_step(hs, hc, ht, lr=1e-4)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tr.train_step(hs, hc, ht, lr=1e-4)
+            line["host_buffer_frames_per_s"] = 5 * B / (time.perf_counter() - t0)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(batch=32, steps=3)
         print(json.dumps(line), flush=True)

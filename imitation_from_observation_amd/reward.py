@@ -1,0 +1,98 @@
+"""The image-feature reward of the reference's TRPO loop, on top of `Translator`.
+
+Restates the `mode == 'ours'` branch of BaseSampler.process_samples (rllab/sampler/base.py:192-257):
+  * once per experiment: translate every demo video into the current context (first rollout frame of
+    each viewpoint) and cache the mean translated feature track and mean translated frames
+    (base.py:195-223);
+  * per path: encode the 25 rollout frames, cost_j = ||means_j - feat_j||^2 + scale * ||imgs_j - x_j||^2
+    summed over viewpoints (base.py:232-245), and  rewards[2j+1] -= cost_j * j^2  (base.py:256-257).
+The arithmetic on the frames runs in the HIP translator; several paths are encoded per launch (the
+encoder is per-frame independent, so results do not depend on the grouping).  The reference's internal
+inconsistencies on this path (SURVEY.md 3.4 e-g) are resolved to the intended behaviour and noted inline.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class TranslatorReward:
+    def __init__(self, translator, nvp, scale, name="strike", ablation_type="None", batch_size=25):
+        if ablation_type not in ("None", "nofeat", "noimage"):
+            # 'recon' reads an undefined `image_recon` in the reference (base.py:250-252)
+            raise NotImplementedError(f"ablation_type {ablation_type!r} is not runnable in the reference either")
+        self.tr, self.nvp, self.scale, self.name = translator, int(nvp), float(scale), name
+        self.ablation_type, self.batch_size = ablation_type, int(batch_size)
+        self.skip = 2 if name in ("real", "sweep") else 1        # base.py:209-211
+        self.means, self.imgs = None, None
+
+    # ------------------------------------------------------------------ base.py:195-223
+    @staticmethod
+    def _frames_of(path):
+        """env_infos['imgs'] holds, every other step, a list over viewpoints of uint8 frames (base.py:193)."""
+        return [img for img in path["env_infos"]["imgs"] if img is not None]
+
+    def build_demo_cache(self, validdata, first_frames):
+        """validdata: demo tensor [T, Nvid, H, W, 3] in [-1,1] (np.load(modeldata), base.py:198);
+        first_frames[vp]: uint8 context frame = first frame of the current rollout (base.py:200)."""
+        validdata = np.asarray(validdata)
+        nvid = validdata.shape[1]
+        bs = self.batch_size
+        self.means, self.imgs = [], []
+        per_call = max(1, self.tr.max_batch // bs)
+        for vp in range(self.nvp):
+            ctx = np.ascontiguousarray(first_frames[vp], dtype=np.uint8)
+            fsum = np.zeros((bs, self.tr.featsize), np.float64)
+            isum = np.zeros((bs, self.tr.H, self.tr.W, 3), np.float64)
+            for i0 in range(0, nvid, per_call):
+                vids = range(i0, min(nvid, i0 + per_call))
+                # ((validdata[::skip, i] + 1) * 127.5).astype(np.uint8), base.py:215
+                u8 = np.concatenate([((validdata[::self.skip, i][:bs] + 1) * 127.5).astype(np.uint8) for i in vids])
+                timg, tfeat = self.tr.translate(u8, ctx)                   # [translated_z, out], base.py:216-218
+                fsum += tfeat.reshape(len(vids), bs, -1).sum(0)
+                isum += timg.reshape(len(vids), bs, self.tr.H, self.tr.W, 3).sum(0)
+            self.means.append((fsum / nvid).astype(np.float32))            # np.mean(tfeats, axis=0), base.py:221
+            self.imgs.append((isum / nvid).astype(np.float32))             # np.mean(timgs, axis=0), base.py:222
+        return self
+
+    # ------------------------------------------------------------------ base.py:232-252
+    def _costs_from(self, feats, frames_f32, vp):
+        cf = np.sum((self.means[vp] - feats) ** 2, axis=1)
+        ci = self.scale * np.sum((self.imgs[vp] - frames_f32) ** 2, axis=(1, 2, 3))
+        if self.ablation_type == "nofeat":      # reference indexes self.imgs without [vp]
+            return ci
+        if self.ablation_type == "noimage":
+            return cf
+        return cf + ci
+
+    def paths_costs(self, paths):
+        """costs[p][j] for every path, many paths per encoder launch."""
+        bs = self.batch_size
+        frames = [self._frames_of(p) for p in paths]
+        for f in frames:
+            if len(f) != bs:
+                raise ValueError(f"a path has {len(f)} rendered frames, the sampler's placeholder holds {bs} (base.py:115)")
+        if self.means is None:
+            raise RuntimeError("build_demo_cache() first (the reference builds it lazily on the first path)")
+        costs = np.zeros((len(paths), bs), np.float32)
+        per_call = max(1, self.tr.max_batch // bs)
+        for vp in range(self.nvp):
+            for p0 in range(0, len(paths), per_call):
+                grp = range(p0, min(len(paths), p0 + per_call))
+                u8 = np.concatenate([np.stack([fr[vp] for fr in frames[p]]).astype(np.uint8) for p in grp])
+                feats, x = self.tr.encode(u8)                              # [input_z, image_trans[0]], base.py:234-235
+                for k, p in enumerate(grp):
+                    sl = slice(k * bs, (k + 1) * bs)
+                    c = self._costs_from(feats[sl], x[sl], vp)
+                    # 'None' accumulates over viewpoints (costs += ...); the ablations overwrite (costs = ...)
+                    costs[p] = costs[p] + c if self.ablation_type == "None" else c
+        return costs
+
+    # ------------------------------------------------------------------ base.py:256-257
+    def process_paths(self, paths):
+        """In place: path['rewards'][2j+1] -= costs[j] * j**2.  Builds the demo cache lazily like the reference
+        when `self.validdata` was provided."""
+        costs = self.paths_costs(paths)
+        for p, c in zip(paths, costs):
+            for j in range(self.batch_size):
+                p["rewards"][j * 2 + 1] -= c[j] * (j ** 2)
+        return costs
