@@ -315,12 +315,16 @@ void bias_grad(ctx_handle* h, const std::string& name, const float* dy, int64_t 
     colsum(h->stream, dy, rows, C, h->scratch, db);
 }
 
-void fc_dw(ctx_handle* h, const std::string& name, const NmPlain& x, int K, const float* dy, int M, int N, float* dw, float* db) {
+void fc_dw_launch(hipStream_t s, const NmPlain& x, const NmPlain& dy, Epi ep, int K, int N, int nch, SplitWs ws) { gemm_fc_dw(s, x, dy, ep, K, N, nch, ws); }
+void fc_dw_launch(hipStream_t s, const NmPlain2& x, const NmPlain& dy, Epi ep, int K, int N, int nch, SplitWs ws) { gemm_fc_dw2(s, x, dy, ep, K, N, nch, ws); }
+
+template <class XL>
+void fc_dw(ctx_handle* h, const std::string& name, const XL& x, int K, const float* dy, int M, int N, float* dw, float* db) {
     {
         ProfScope ps(h, name + " dw", K_FCDW, 2.0 * M * K * N);
         Epi ep;
         ep.out1 = dw; ep.ld1 = N;
-        gemm_fc_dw(h->stream, x, nm(dy, N, N, M), ep, K, N, (M + KC - 1) / KC, ws_of(h));
+        fc_dw_launch(h->stream, x, nm(dy, N, N, M), ep, K, N, (M + KC - 1) / KC, ws_of(h));
     }
     bias_grad(h, name, dy, M, N, db);
 }
@@ -438,7 +442,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
         bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
         const double fl = 2.0 * R * 25 * cb * ca;
-        NmWgradSmall small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
+        NmWgradSmall2 small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
         Epi eg;
         eg.out1 = h->Gp((nm_ + "/w").c_str()); eg.ld1 = cb;
         // input gradient = SAME stride-2 conv of dy with the same filter read as [5,5,ca,cb]; cols < c1
@@ -447,10 +451,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
         if (ca == 3) {
-            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad(s, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(s, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws); }
             { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws); }
         } else {
-            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad2(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
               conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
         }
@@ -470,7 +474,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         Epi e1;
         e1.out1 = h->dth0; e1.ld1 = F; e1.mask = h->th0; e1.ldm = F;
         fc_dx(h, "translate/trans_z", h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
-        NmPlain tcat{src_z, F, h->cz, F, F, 2 * F, B, g_zeros};
+        NmPlain2 tcat{src_z, F, h->cz, F, F, 2 * F, B, g_zeros};
         fc_dw(h, "translate/trans_h0", tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
         Epi e2;   // d concat: cols < F -> d src_z (row block 2 of dZ), cols >= F -> d ctx_z
         e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;

@@ -4,13 +4,13 @@
 namespace ctx {
 void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, int M, int N, SplitWs ws) {
     NmPlain b = b_;
-    b.seglen = a.cps * KC;     // filter rows in KmConvGather's K order
-    launch_igemm(s, a, b, ep, M, N, 1, 25 * a.cps, ws);
+    b.seglen = a.tap_outer ? 0 : a.cps * KC;     // filter rows in KmConvGather's K order (A/B measured: no difference)
+    launch_igemm<KmConvGather, NmPlain, true>(s, a, b, ep, M, N, 1, 25 * a.cps, ws);
 }
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     ep.rowmode = 1; ep.hs = a.hs; ep.ws = a.ws;
     // no split-K here: the four parity classes have different K extents and M is the pixel count
-    launch_igemm(s, a, b, ep, M, N, 4, 0, ws);
+    launch_igemm<KmConvTGather, KmConvTWeights, true>(s, a, b, ep, M, N, 4, 0, ws);
 }
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws) {
     // B[k][n] = w[ky,kx,c,k] with n = (ky*5+kx)*3+c: the filter itself, rows n contiguous in k

@@ -8,27 +8,37 @@ namespace ctx {
 
 void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);
 
-template <class LA, class LB, int MI, int NI>
+template <class LA, class LB, int MI, int NI, int WM, int WN>
 static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
-    constexpr int TM = 64 * MI, TN = 64 * NI;
+    constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
-    constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM>::FLOATS + Tile<LB::KM, TN>::FLOATS) * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM, NT>::FLOATS + Tile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
     static bool raised = false;
     if (lds > 65536 && !raised) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<LA, LB, MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<LA, LB, MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         raised = true;
     }
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
     dim3 grid((unsigned)((int64_t)gm * gn * nprob * nsplit));
-    hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI>), grid, dim3(NTHREADS), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
+    hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 
 // Blocks wanted before the K loop is split: 256 CUs x ~3 resident blocks.
 constexpr int64_t TARGET_BLOCKS = 768;
 
-template <class LA, class LB>
+// BIG = the 8-wave 256x256 tile is instantiated for this loader pair
+template <class LA, class LB, bool BIG = false>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
                          SplitWs ws) {
+    static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
+    if constexpr (BIG) {
+        const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
+        if (force != 1 && M >= 256 && N >= 256 && (big_tiles >= 192 || force == 2)) {
+            ep.slab = nullptr;
+            launch_tile<LA, LB, 2, 4, 4, 2>(s, a, b, ep, M, N, nprob, 1);
+            return;
+        }
+    }
     const int MI = M > 64 ? 2 : 1, NI = N > 64 ? 2 : 1;
     const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
     int nsplit = 1;
@@ -42,10 +52,10 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         if (n > 1) nsplit = (int)n;
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
-    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
-    else if (MI == 2) launch_tile<LA, LB, 2, 1>(s, a, b, ep, M, N, nprob, nsplit);
-    else if (NI == 2) launch_tile<LA, LB, 1, 2>(s, a, b, ep, M, N, nprob, nsplit);
-    else launch_tile<LA, LB, 1, 1>(s, a, b, ep, M, N, nprob, nsplit);
+    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else if (MI == 2) launch_tile<LA, LB, 2, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else if (NI == 2) launch_tile<LA, LB, 1, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else launch_tile<LA, LB, 1, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
     if (nsplit > 1) splitk_reduce(s, ep, M, N, nprob, nsplit);
 }
 

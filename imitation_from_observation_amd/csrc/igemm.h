@@ -138,11 +138,32 @@ __device__ __forceinline__ void epi_store(const Epi& e, int prob, int64_t pix, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Loaders.  KM loaders: prep(prob,row,ctx) once per tile row, then load(ctx,prob,chunk,k4) -> 4
-//           consecutive k.  NM loaders: load(prob,chunk,kk,r4) -> rows r4..r4+3 at k = chunk*32+kk.
-// All are branch-free and return zeros outside the virtual matrix (SAME padding, ragged M/N/K) by
-// redirecting the load to `zeros`.
+// Loaders.  Measured (rocprofv3 PMC): the first version spent 3-15 ALU instructions per MFMA on
+// per-load address / validity math, and an in-order wave cannot hide that behind a 64-cycle MFMA.
+// Hence the split used here:
+//   Pos  pos(prob, chunk)            wave-uniform, computed ONCE per chunk on the scalar unit: which tap /
+//                                    channel slice / source tensor; folded into the BASE of a buffer
+//                                    descriptor (so no per-lane add is needed for it)
+//   void prep(prob, a, b, Ctx&)      per-lane, loop-invariant: byte offset of this lane's float4 inside
+//                                    the tensor (a,b = row,k4 for KM loaders; kk,r4 for NM loaders) and
+//                                    its tap-validity bit mask
+//   float4 load(Ctx, Pos)            one raw_buffer_load_b128; lanes that fall into SAME padding or past
+//                                    a ragged edge get voffset = OOB >= num_records and the hardware
+//                                    returns zeros -- no pointer select, no branch, no zero page.
+// Descriptors are built with num_records = 2 GiB: every tensor here is far smaller, so the range check
+// only ever fires for the OOB marker.
 // ------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr uint32_t OOB = 0x80000000u;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)0x80000000, 0x00020000);
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 bload4(rsrc_t r, uint32_t voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 // Plain row-major matrix V[row][k], optionally split along k into two buffers (the translate MLP's
 // concat([src_z, ctx_z]), arm_shaping.py:1310).
@@ -153,22 +174,26 @@ struct KmPlain {
     int ksplit;      // k < ksplit -> p0, else p1[k - ksplit]; a multiple of KC
     int R;           // valid rows
     int nchunks;
-    const float* zeros;
-    struct Ctx { const float* r0; const float* r1; bool ok; };
+    const float* zeros;   // unused (kept so host initialisers are uniform)
+    struct Pos { rsrc_t rs; bool second; };
+    struct Ctx { uint32_t v0, v1; };
     __device__ int nchunks_of(int) const { return nchunks; }
-    __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
-        c.r0 = p0 + (int64_t)row * ld0;
-        c.r1 = p1 + (int64_t)row * ld1 - ksplit;
+    __device__ Pos pos(int, int chunk) const {
+        const int k0 = chunk * KC;
+        const bool second = k0 >= ksplit;
+        return Pos{make_rsrc(second ? p1 + (k0 - ksplit) : p0 + k0), second};
     }
-    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        const int k = chunk * KC + k4;
-        return ldg4_or0((chunk * KC < ksplit ? c.r0 : c.r1) + k, c.ok, zeros);
+    __device__ void prep(int, int row, int k4, Ctx& c) const {
+        const bool ok = row < R;
+        c.v0 = ok ? (uint32_t)(row * ld0 + k4) * 4u : OOB;
+        c.v1 = ok ? (uint32_t)(row * ld1 + k4) * 4u : OOB;
     }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v1 : c.v0); }
 };
 
 // conv2d forward operand: row m = (img, i, j) of the OUTPUT grid; segment = tap (ky,kx); the run is
 // the cin channels of input pixel (2i+ky-1, 2j+kx-1)  [TF SAME for k=5, s=2, even input: pad 1 / 2].
+// K order: 32-channel slice outer, the 25 taps inner.
 struct KmConvGather {
     static constexpr bool KM = true;
     const float* x; int64_t ldx;   // NHWC input, channel stride ldx
@@ -176,12 +201,21 @@ struct KmConvGather {
     int cps;                       // chunks per tap = cin / 32
     int R;                         // imgs * hs * ws
     const float* zeros;
-    struct Ctx { const float* base; unsigned mask; };   // base -> input pixel (2i-1, 2j-1); mask bit = tap valid
+    int tap_outer = 0;             // K order: 0 = channel slice outer / taps inner, 1 = taps outer
+    struct Pos { rsrc_t rs; int seg; };
+    struct Ctx { uint32_t v; unsigned mask; };   // v -> input pixel (2i, 2j); mask bit = tap valid
     __device__ int nchunks_of(int) const { return 25 * cps; }
-    __device__ void prep(int, int row, Ctx& c) const {
+    __device__ Pos pos(int, int chunk) const {
+        int seg, slice;
+        if (tap_outer) { seg = chunk / cps; slice = chunk - seg * cps; }
+        else tap_slice(chunk, 25, seg, slice);
+        const int ky = seg / 5, kx = seg - ky * 5;
+        return Pos{make_rsrc(x + ((int64_t)(ky - 1) * wb + (kx - 1)) * ldx + slice * KC), seg};
+    }
+    __device__ void prep(int, int row, int k4, Ctx& c) const {
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
         const int i2 = 2 * i - 1, j2 = 2 * j - 1;
-        c.base = x + (((int64_t)n * hb + i2) * wb + j2) * ldx;
+        c.v = (uint32_t)((((int64_t)n * hb + 2 * i) * wb + 2 * j) * ldx + k4) * 4u;
         unsigned m = 0;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky)
@@ -190,16 +224,7 @@ struct KmConvGather {
                 if ((unsigned)(i2 + ky) < (unsigned)hb && (unsigned)(j2 + kx) < (unsigned)wb) m |= 1u << (ky * 5 + kx);
         c.mask = row < R ? m : 0u;
     }
-    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        // K order: 32-channel slice outer, the 25 taps inner -- a block re-reads one slice of its input
-        // halo (L2-resident) 25 times before moving to the next slice
-        int seg, slice;
-        tap_slice(chunk, 25, seg, slice);                                 // wave-uniform
-        const int kc = slice * KC;
-        const int ky = seg / 5, kx = seg - ky * 5;
-        const int64_t off = (int64_t)(ky * wb + kx) * ldx + kc;           // wave-uniform
-        return ldg4_or0(c.base + off + k4, (c.mask >> seg) & 1u, zeros);
-    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, (c.mask >> q.seg) & 1u ? c.v : OOB); }
 };
 
 // conv2d_transpose operand for output parity class prob = (py,px): row m = (img, i', j') with output
@@ -214,14 +239,25 @@ struct KmConvTGather {
     int cps;                       // (c1 + c2) / 32
     int R;
     const float* zeros;
-    struct Ctx { const float* b1; const float* b2; unsigned mask; };   // b* -> input pixel (i'+py, j'+px)
+    struct Pos { rsrc_t rs; int bit; bool second; };
+    struct Ctx { uint32_t v1, v2; unsigned mask; };   // v* -> input pixel (i', j')
     __device__ int nchunks_of(int prob) const { return (2 + (prob >> 1)) * (2 + (prob & 1)) * cps; }
-    __device__ void prep(int prob, int row, Ctx& c) const {
+    __device__ Pos pos(int prob, int chunk) const {
+        const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
+        int seg, slice;
+        tap_slice(chunk, ntap, seg, slice);
+        const int kc = slice * KC;
+        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
+        const int64_t d = (int64_t)(py - sy) * ws + (px - sx);          // pixel shift of this tap
+        const bool second = kc >= c1;
+        return Pos{make_rsrc(second ? s2 + d * ld2 + (kc - c1) : s1 + d * ld1 + kc), sy * 3 + sx, second};
+    }
+    __device__ void prep(int prob, int row, int k4, Ctx& c) const {
         const int py = prob >> 1, px = prob & 1;
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        const int64_t pix = (int64_t)(i + py) * ws + (j + px);
-        c.b1 = s1 + ((int64_t)n * hs * ws + pix) * ld1;
-        c.b2 = s2 + ((int64_t)(n % nmod2) * hs * ws + pix) * ld2 - c1;
+        const int64_t pix = (int64_t)i * ws + j;
+        c.v1 = (uint32_t)(((int64_t)n * hs * ws + pix) * ld1 + k4) * 4u;
+        c.v2 = (uint32_t)(((int64_t)(n % nmod2) * hs * ws + pix) * ld2 + k4) * 4u;
         unsigned m = 0;
 #pragma unroll
         for (int sy = 0; sy < 3; ++sy)
@@ -230,15 +266,8 @@ struct KmConvTGather {
                 if ((unsigned)(i + py - sy) < (unsigned)hs && (unsigned)(j + px - sx) < (unsigned)ws) m |= 1u << (sy * 3 + sx);
         c.mask = row < R ? m : 0u;
     }
-    __device__ float4 load(const Ctx& c, int prob, int chunk, int k4) const {
-        const int ntx = 2 + (prob & 1), ntap = (2 + (prob >> 1)) * ntx;
-        int seg, slice;
-        tap_slice(chunk, ntap, seg, slice);                               // wave-uniform; slice outer, taps inner
-        const int kc = slice * KC;
-        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
-        const int poff = sy * ws + sx;                                    // pixels back from (i'+py, j'+px)
-        const float* p = kc < c1 ? c.b1 - (int64_t)poff * ld1 : c.b2 - (int64_t)poff * ld2;
-        return ldg4_or0(p + kc + k4, (c.mask >> (sy * 3 + sx)) & 1u, zeros);
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        return bload4(q.rs, (c.mask >> q.bit) & 1u ? (q.second ? c.v2 : c.v1) : OOB);
     }
 };
 
@@ -248,18 +277,19 @@ struct KmConvTWeights {
     const float* w; int ca, cb;    // cb = c1 + c2
     int cps;
     const float* zeros;
-    struct Ctx { const float* rowp; bool ok; };
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
     __device__ int nchunks_of(int) const { return 0; }
-    __device__ void prep(int, int row, Ctx& c) const { c.ok = row < ca; c.rowp = w + (int64_t)row * cb; }
-    __device__ float4 load(const Ctx& c, int prob, int chunk, int k4) const {
+    __device__ Pos pos(int prob, int chunk) const {
         const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
         int seg, slice;
-        tap_slice(chunk, ntap, seg, slice);                               // same K order as KmConvTGather
-        const int kc = slice * KC;
+        tap_slice(chunk, ntap, seg, slice);
         const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
         const int ky = 1 - py + 2 * sy, kx = 1 - px + 2 * sx;
-        return ldg4_or0(c.rowp + (int64_t)(ky * 5 + kx) * ca * cb + kc + k4, c.ok, zeros);
+        return Pos{make_rsrc(w + (int64_t)(ky * 5 + kx) * ca * cb + slice * KC)};
     }
+    __device__ void prep(int, int row, int k4, Ctx& c) const { c.v = row < ca ? (uint32_t)(row * cb + k4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
 };
 
 // Per-pixel channel vectors of the decoder's concat input [s1 | s2]: row m = pixel (img,i,j), k =
@@ -272,45 +302,51 @@ struct KmCat2 {
     int R;           // pixels
     int cps;         // (c1 + c2) / 32
     const float* zeros;
-    struct Ctx { const float* p1; const float* p2; bool ok; };
+    struct Pos { rsrc_t rs; bool second; };
+    struct Ctx { uint32_t v1, v2; };
     __device__ int nchunks_of(int) const { return cps; }
-    __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
+    __device__ Pos pos(int, int chunk) const {
+        const int k0 = chunk * KC;
+        const bool second = k0 >= c1;
+        return Pos{make_rsrc(second ? s2 + (k0 - c1) : s1 + k0), second};
+    }
+    __device__ void prep(int, int row, int k4, Ctx& c) const {
+        const bool ok = row < R;
         const int n = row / hsws, rem = row - n * hsws;
-        c.p1 = s1 + (int64_t)row * ld1;
-        c.p2 = s2 + ((int64_t)(n % nmod2) * hsws + rem) * ld2 - c1;
+        c.v1 = ok ? (uint32_t)((int64_t)row * ld1 + k4) * 4u : OOB;
+        c.v2 = ok ? (uint32_t)(((int64_t)(n % nmod2) * hsws + rem) * ld2 + k4) * 4u : OOB;
     }
-    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        const int k = chunk * KC + k4;
-        return ldg4_or0((chunk * KC < c1 ? c.p1 : c.p2) + k, c.ok, zeros);
-    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v2 : c.v1); }
 };
 
 // conv2d forward operand when cin == 3 (the frame itself, or the decoder's output gradient): for a
 // fixed ky the 5 taps x 3 channels of a row are 15 CONTIGUOUS floats starting at pixel (.., 2j-1).
-// A chunk holds two ky segments of 16 (15 + one zero); 3 chunks cover ky = 0..4.
+// A chunk holds two ky segments of 16 (15 + one zero); 3 chunks cover ky = 0..4.  (5 % of a step:
+// kept on scalar element loads with a zero page.)
 struct KmC3Gather {
     static constexpr bool KM = true;
     const float* x;
     int hb, wb, hs, ws;
     int R;
     const float* zeros;
-    struct Ctx { const float* base; int i2, j2; bool ok; };   // base -> element (2i-1, 2j-1, 0)
+    struct Pos { int chunk; };
+    struct Ctx { const float* base; int i2, j2, k4; bool ok; };   // base -> element (2i-1, 2j-1, 0)
     __device__ int nchunks_of(int) const { return 3; }
-    __device__ void prep(int, int row, Ctx& c) const {
-        c.ok = row < R;
+    __device__ Pos pos(int, int chunk) const { return Pos{chunk}; }
+    __device__ void prep(int, int row, int k4, Ctx& c) const {
+        c.ok = row < R; c.k4 = k4;
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
         c.i2 = 2 * i - 1; c.j2 = 2 * j - 1;
         c.base = x + (((int64_t)n * hb + c.i2) * wb + c.j2) * 3;
     }
-    __device__ float4 load(const Ctx& c, int, int chunk, int k4) const {
-        const int ky = 2 * chunk + (k4 >> 4);
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const int ky = 2 * q.chunk + (c.k4 >> 4);
         const bool rowok = c.ok && ky < 5 && (unsigned)(c.i2 + ky) < (unsigned)hb;
         const float* rowp = c.base + (int64_t)ky * wb * 3;
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int el = (k4 & 15) + u;        // (kx, ch) = (el / 3, el % 3)
+            const int el = (c.k4 & 15) + u;        // (kx, ch) = (el / 3, el % 3)
             const bool ok = rowok && el < 15 && (unsigned)(c.j2 + el / 3) < (unsigned)wb;
             v[u] = *(ok ? rowp + el : zeros);
         }
@@ -318,27 +354,63 @@ struct KmC3Gather {
     }
 };
 
-// Plain k-major matrix V[k][r], optionally split along r into two buffers; ragged K allowed.
+// Plain k-major matrix V[k][r] (single buffer); ragged K allowed.  seglen > 0: the conv filter
+// [25][cin][cout] read in KmConvGather's K order (slice outer, tap inner).
 struct NmPlain {
     static constexpr bool KM = false;
     const float* p0; int64_t ld0;
-    const float* p1; int64_t ld1;
-    int rsplit;      // r < rsplit -> p0, else p1[r - rsplit]
+    const float* p1; int64_t ld1;   // unused here (see NmPlain2)
+    int rsplit;
     int R;           // valid r
     int K;           // valid k
     const float* zeros;
-    int seglen = 0;  // > 0: K = 25 tap segments of seglen rows, chunk order (slice outer, tap inner) to match
-                     //      KmConvGather -- the conv filter [25][cin][cout]
+    int seglen = 0;
+    struct Pos { rsrc_t rs; int kleft; };
+    struct Ctx { uint32_t v; int kk; };
     __device__ int nchunks_of(int) const { return (K + KC - 1) / KC; }
-    __device__ float4 load(int, int chunk, int kk, int r4) const {
-        int k = chunk * KC + kk;
+    __device__ Pos pos(int, int chunk) const {
+        int k0 = chunk * KC;
         if (seglen) {
             int seg, slice;
             tap_slice(chunk, 25, seg, slice);
-            k = seg * seglen + slice * KC + kk;
+            k0 = seg * seglen + slice * KC;
         }
-        const float* p = r4 < rsplit ? p0 + (int64_t)k * ld0 + r4 : p1 + (int64_t)k * ld1 + (r4 - rsplit);
-        return ldg4_or0(p, k < K && r4 < R, zeros);
+        return Pos{make_rsrc(p0 + (int64_t)k0 * ld0), K - chunk * KC};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.kk = kk;
+        c.v = r4 < R ? (uint32_t)((int64_t)kk * ld0 + r4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.kk < q.kleft ? c.v : OOB); }
+};
+
+// V[k][r] = [p0 | p1] split along r at rsplit (the Matrix gradient of trans_h0, whose input is
+// concat([src_z, ctx_z])).  A lane belongs to exactly one buffer; both loads are issued and the other
+// one returns zeros.
+struct NmPlain2 {
+    static constexpr bool KM = false;
+    const float* p0; int64_t ld0;
+    const float* p1; int64_t ld1;
+    int rsplit;
+    int R;
+    int K;
+    const float* zeros;
+    struct Pos { rsrc_t r0, r1; int kleft; };
+    struct Ctx { uint32_t v0, v1; int kk; };
+    __device__ int nchunks_of(int) const { return (K + KC - 1) / KC; }
+    __device__ Pos pos(int, int chunk) const {
+        const int64_t k0 = (int64_t)chunk * KC;
+        return Pos{make_rsrc(p0 + k0 * ld0), make_rsrc(p1 + k0 * ld1), K - chunk * KC};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.kk = kk;
+        c.v0 = r4 < rsplit ? (uint32_t)((int64_t)kk * ld0 + r4) * 4u : OOB;
+        c.v1 = (r4 >= rsplit && r4 < R) ? (uint32_t)((int64_t)kk * ld1 + (r4 - rsplit)) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const bool ok = c.kk < q.kleft;
+        const float4 a = bload4(q.r0, ok ? c.v0 : OOB), b = bload4(q.r1, ok ? c.v1 : OOB);
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
 };
 
@@ -347,9 +419,13 @@ struct NmC3Weights {
     static constexpr bool KM = false;
     const float* w; int cb;
     const float* zeros;
-    __device__ float4 load(int, int chunk, int kk, int r4) const {
-        const int ky = 2 * chunk + (kk >> 4), el = kk & 15;
-        return ldg4_or0(w + (int64_t)(ky * 15 + el) * cb + r4, ky < 5 && el < 15 && r4 < cb, zeros);
+    struct Pos { int chunk; };
+    struct Ctx { int kk, r4; };
+    __device__ Pos pos(int, int chunk) const { return Pos{chunk}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r4 = r4; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const int ky = 2 * q.chunk + (c.kk >> 4), el = c.kk & 15;
+        return ldg4_or0(w + (int64_t)(ky * 15 + el) * cb + c.r4, ky < 5 && el < 15 && c.r4 < cb, zeros);
     }
 };
 
@@ -362,34 +438,73 @@ struct NmWgradBig {
     PixDiv pd;
     int npix;        // imgs * hs * ws
     const float* zeros;
+    struct Pos { rsrc_t rs; int k0, ky, kx; };
+    struct Ctx { int kk; uint32_t r; };           // r = channel byte offset or OOB
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
-    __device__ float4 load(int prob, int chunk, int kk, int r4) const {
-        const int p = chunk * KC + kk;
+    __device__ Pos pos(int prob, int chunk) const {
         const int ky = prob / 5, kx = prob - ky * 5;
+        return Pos{make_rsrc(big), chunk * KC, ky, kx};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r = r4 < ca ? (uint32_t)r4 * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const int p = q.k0 + c.kk;
         int n, i, j;
         pd.split(p, n, i, j);
-        const int y = 2 * i + ky - 1, xx = 2 * j + kx - 1;
-        const bool ok = p < npix && r4 < ca && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb;
-        return ldg4_or0(big + (((int64_t)n * hb + y) * wb + xx) * ldb + r4, ok, zeros);
+        const int y = 2 * i + q.ky - 1, xx = 2 * j + q.kx - 1;
+        const bool ok = p < npix && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb;
+        const uint32_t v = (uint32_t)(((n * hb + y) * wb + xx) * (int)ldb) * 4u + c.r;   // c.r == OOB keeps it out of range
+        return bload4(q.rs, ok ? v : OOB);
     }
 };
 
-// Filter-gradient operand, small side: k = pixel, rows = channels of [s1 | s2] (s2 = ctx skip, image
-// index img % nmod2).  Single-source tensors pass c1 = total channels.
+// Filter-gradient operand, small side, single tensor: k = pixel, rows = channels.
 struct NmWgradSmall {
+    static constexpr bool KM = false;
+    const float* s1; int64_t ld1; int c1;
+    const float* s2; int64_t ld2; int nmod2;      // unused here (see NmWgradSmall2)
+    int cb;
+    int hsws;
+    int hsws_sh;
+    int npix;
+    const float* zeros;
+    struct Pos { rsrc_t rs; int kleft; };
+    struct Ctx { uint32_t v; int kk; };
+    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(s1 + (int64_t)chunk * KC * ld1), npix - chunk * KC}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.kk = kk;
+        c.v = r4 < cb ? (uint32_t)((int64_t)kk * ld1 + r4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.kk < q.kleft ? c.v : OOB); }
+};
+
+// Small side of a decoder filter gradient: channels of [s1 | s2], s2 = ctx skip with image index
+// img % nmod2 (img < 2 * nmod2: the two decoder passes).  Both loads are issued; a lane's other one is OOB.
+struct NmWgradSmall2 {
     static constexpr bool KM = false;
     const float* s1; int64_t ld1; int c1;
     const float* s2; int64_t ld2; int nmod2;
     int cb;          // c1 + c2
     int hsws;        // pixels per image
-    int hsws_sh;     // log2(hsws) or -1
+    int hsws_sh;
     int npix;
     const float* zeros;
-    __device__ float4 load(int, int chunk, int kk, int r4) const {
-        const int p = chunk * KC + kk;
-        const int n = hsws_sh >= 0 ? p >> hsws_sh : p / hsws, rem = p - n * hsws;
-        const float* q = r4 < c1 ? s1 + (int64_t)p * ld1 + r4 : s2 + ((int64_t)(n % nmod2) * hsws + rem) * ld2 + (r4 - c1);
-        return ldg4_or0(q, p < npix && r4 < cb, zeros);
+    struct Pos { rsrc_t r1, r2; int k0, kleft; };
+    struct Ctx { uint32_t v1, r2; int kk; };       // r2 = channel byte offset inside s2, or OOB
+    __device__ Pos pos(int, int chunk) const {
+        return Pos{make_rsrc(s1 + (int64_t)chunk * KC * ld1), make_rsrc(s2), chunk * KC, npix - chunk * KC};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.kk = kk;
+        c.v1 = r4 < c1 ? (uint32_t)((int64_t)kk * ld1 + r4) * 4u : OOB;
+        c.r2 = (r4 >= c1 && r4 < cb) ? (uint32_t)(r4 - c1) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const bool ok = c.kk < q.kleft;
+        const int p = q.k0 + c.kk, wrap = nmod2 * hsws;
+        const int p2 = p >= wrap ? p - wrap : p;                          // pixel of image img % nmod2
+        const float4 a = bload4(q.r1, ok ? c.v1 : OOB);
+        const float4 b = bload4(q.r2, ok ? (uint32_t)(p2 * (int)ld2) * 4u + c.r2 : OOB);
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     }
 };
 
@@ -401,10 +516,14 @@ struct NmC3WgradBig {
     PixDiv pd;
     int npix;
     const float* zeros;
+    struct Pos { int k0; };
+    struct Ctx { int kk, r4; };
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
-    __device__ float4 load(int, int chunk, int kk, int r4) const {
-        const int p = chunk * KC + kk;
-        const int ky = r4 >> 4;
+    __device__ Pos pos(int, int chunk) const { return Pos{chunk * KC}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r4 = r4; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const int p = q.k0 + c.kk;
+        const int ky = c.r4 >> 4;
         int n, i, j;
         pd.split(p, n, i, j);
         const int y = 2 * i + ky - 1, j2 = 2 * j - 1;
@@ -413,7 +532,7 @@ struct NmC3WgradBig {
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int el = (r4 & 15) + u;
+            const int el = (c.r4 & 15) + u;
             const bool ok = rowok && el < 15 && (unsigned)(j2 + el / 3) < (unsigned)wb;
             v[u] = *(ok ? rowp + el : zeros);
         }
@@ -422,16 +541,17 @@ struct NmC3WgradBig {
 };
 
 // ------------------------------------------------------------------------------------------------
-// LDS tiles
+// LDS tiles.  NT = threads of the block that cooperate on a tile.
 // ------------------------------------------------------------------------------------------------
-template <bool KMF, int TR>
+template <bool KMF, int TR, int NT>
 struct Tile {
     static constexpr int FLOATS = KMF ? TR * LDK : KC * TR;
-    static constexpr int NPASS = TR / 32;     // float4 per thread per chunk
+    static constexpr int NPASS = TR * KC / 4 / NT;     // float4 per thread per chunk
+    static_assert(NPASS >= 1, "tile too small for the block");
     // global row (KM) handled by thread tid in pass p
-    __device__ static int km_row(int tid, int p) { return (tid >> 3) + 32 * p; }
+    __device__ static int km_row(int tid, int p) { return (tid >> 3) + (NT / 8) * p; }
     __device__ static int km_k4(int tid) { return (tid & 7) * 4; }
-    __device__ static int nm_kk(int tid, int p) { return tid / (TR / 4) + (NTHREADS / (TR / 4)) * p; }
+    __device__ static int nm_kk(int tid, int p) { return tid / (TR / 4) + (NT / (TR / 4)) * p; }
     __device__ static int nm_r4(int tid) { return (tid % (TR / 4)) * 4; }
     __device__ static void store(float* s, int tid, int p, float4 v) {
         if (KMF) *reinterpret_cast<float4*>(&s[km_row(tid, p) * LDK + km_k4(tid)]) = v;
@@ -449,44 +569,43 @@ struct Tile {
     }
 };
 
-// per-thread view of a loader: which float4 of a chunk this thread fetches in pass p
-template <class L, int TR, bool KMF = L::KM>
-struct Fetch;
-template <class L, int TR>
-struct Fetch<L, TR, true> {
-    typename L::Ctx c[TR / 32];
+// per-thread view of a loader: the loop-invariant state of the float4 this thread fetches in pass p
+template <class L, int TR, int NT>
+struct Fetch {
+    using T = Tile<L::KM, TR, NT>;
+    typename L::Ctx c[T::NPASS];
     __device__ void init(const L& l, int prob, int row0, int tid) {
 #pragma unroll
-        for (int p = 0; p < TR / 32; ++p) l.prep(prob, row0 + Tile<true, TR>::km_row(tid, p), c[p]);
+        for (int p = 0; p < T::NPASS; ++p) {
+            if (L::KM) l.prep(prob, row0 + T::km_row(tid, p), T::km_k4(tid), c[p]);
+            else l.prep(prob, T::nm_kk(tid, p), row0 + T::nm_r4(tid), c[p]);
+        }
     }
-    __device__ float4 load1(const L& l, int prob, int, int chunk, int tid, int p) const {
-        return l.load(c[p], prob, chunk, Tile<true, TR>::km_k4(tid));
-    }
-};
-template <class L, int TR>
-struct Fetch<L, TR, false> {
-    __device__ void init(const L&, int, int, int) {}
-    __device__ float4 load1(const L& l, int prob, int row0, int chunk, int tid, int p) const {
-        return l.load(prob, chunk, Tile<false, TR>::nm_kk(tid, p), row0 + Tile<false, TR>::nm_r4(tid));
-    }
+    __device__ float4 load1(const L& l, const typename L::Pos& q, int p) const { return l.load(c[p], q); }
 };
 
 // ------------------------------------------------------------------------------------------------
-// The kernel.  1-D grid of gm * gn * nprob * nsplit blocks.
+// The kernel.  1-D grid of gm * gn * nprob * nsplit blocks; a block is WM x WN waves, each wave owns
+// (32*MI) x (32*NI) of the (32*MI*WM) x (32*NI*WN) block tile.  Shipped shapes:
+//   4 waves (2x2), wave 64x64 or smaller  -> 128x128 ... 64x64 tiles   (small M or N)
+//   8 waves (4x2), wave 64x128            -> 256x256 tile: half the HBM/L2 bytes per MFMA of 128x128
 // ------------------------------------------------------------------------------------------------
-
-template <class LA, class LB, int MI, int NI>
-__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB lb, const Epi ep, int M, int N,
-                                                         int nprob, int nsplit, int gm, int gn) {
-    constexpr int TM = 64 * MI, TN = 64 * NI;
-    using TA = Tile<LA::KM, TM>;
-    using TB = Tile<LB::KM, TN>;
-    constexpr int NA = TA::NPASS, NB = TB::NPASS;       // float4 per thread per chunk: 2..4 each
+template <class LA, class LB, int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const LB lb, const Epi ep, int M, int N,
+                                                             int nprob, int nsplit, int gm, int gn) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int TM = 32 * MI * WM, TN = 32 * NI * WN;
+    using TA = Tile<LA::KM, TM, NT>;
+    using TB = Tile<LB::KM, TN, NT>;
+    constexpr int NA = TA::NPASS, NB = TB::NPASS;       // float4 per thread per chunk
+    static_assert(NA + NB <= 8, "one load and one store slot per MFMA group");
     constexpr int STAGE = TA::FLOATS + TB::FLOATS;
+    // two register sets (1.5-chunk prefetch distance) only where the register file has room
+    constexpr bool TWO_SETS = MI * NI <= 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages of [A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, h = lane >> 5;
+    const int wm = wv / WN, wn = wv % WN, l31 = lane & 31, h = lane >> 5;
 
     // 1-D grid, m-tile fastest, then n-tile, then problem, then K-split.  Problems go last-first: the
     // (1,1) parity class of a transposed conv has 9 taps against 4 for (0,0), and the longest blocks
@@ -503,8 +622,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB l
     const int cb = split * per;
     const int ce = (cb + per < nch) ? cb + per : nch;
 
-    Fetch<LA, TM> fa;
-    Fetch<LB, TN> fb;
+    Fetch<LA, TM, NT> fa;      // per-lane invariants of this thread's float4s
+    Fetch<LB, TN, NT> fb;
     fa.init(la, prob, m0, tid);
     fb.init(lb, prob, n0, tid);
 
@@ -518,64 +637,86 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB l
 
     if (cb < ce) {
         const int last = ce - 1;
-        // Two register sets: while chunk c is multiplied out of LDS stage c&1, set X (chunk c+1, loaded
-        // during chunk c-1) is stored to the other stage in the SECOND half of the MFMA stream and set Y
-        // is refilled with chunk c+2 in the FIRST half -- 1.5 chunks (>= 6000 cycles) between a load's
-        // issue and its first use, which covers an L2 miss to Infinity Cache / HBM.
-        float4 xa[NA], xb[NB], ya[NA], yb[NB];
         auto clampc = [&](int c) { return c < last ? c : last; };   // redundant tail reloads are harmless
+        float4 xa[NA], xb[NB], ya[TWO_SETS ? NA : 1], yb[TWO_SETS ? NB : 1];
         // prologue: chunk cb -> stage 0 ; chunk cb+1 -> set X
+        {
+            const typename LA::Pos qa = la.pos(prob, cb);
+            const typename LB::Pos qb = lb.pos(prob, cb);
 #pragma unroll
-        for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, prob, m0, cb, tid, p);
+            for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
-        for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, prob, n0, cb, tid, p);
+            for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, qb, p);
+        }
 #pragma unroll
         for (int p = 0; p < NA; ++p) TA::store(smem, tid, p, xa[p]);
 #pragma unroll
         for (int p = 0; p < NB; ++p) TB::store(smem + TA::FLOATS, tid, p, xb[p]);
+        {
+            const typename LA::Pos qa = la.pos(prob, clampc(cb + 1));
+            const typename LB::Pos qb = lb.pos(prob, clampc(cb + 1));
 #pragma unroll
-        for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, prob, m0, clampc(cb + 1), tid, p);
+            for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
-        for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, prob, n0, clampc(cb + 1), tid, p);
+            for (int p = 0; p < NB; ++p) xb[p] = fb.load1(lb, qb, p);
+        }
         __syncthreads();
 
-        // one chunk: multiply stage `st`; slots 0..7 load chunk c+2 into (la_, lb_); slots 8..15 store
-        // (sa_, sb_) = chunk c+1 into the other stage
-        auto chunk = [&](int c, int st, float4 (&la_)[NA], float4 (&lb_)[NB], float4 (&sa_)[NA], float4 (&sb_)[NB]) {
+        // One chunk: multiply LDS stage `st` (16 MFMA groups (q,t) of MI*NI instructions).  In the gaps:
+        //  TWO_SETS : groups 0..7 load chunk c+2 into (la_, lb_); groups 8..15 store (sa_, sb_) = chunk c+1
+        //  one set  : groups 0..7 store (sa_, sb_) = chunk c+1;   groups 8..15 reload the same set with c+2
+        auto chunk = [&](int c, int st, float4* la_, float4* lb_, float4* sa_, float4* sb_) {
             const float* sA = smem + st * STAGE;
             const float* sB = sA + TA::FLOATS;
             float* nA = smem + (st ^ 1) * STAGE;
             float* nB = nA + TA::FLOATS;
-            const int c2 = clampc(c + 2);
+            // where chunk c+2 lives: wave-uniform, once per chunk, on the scalar unit
+            const typename LA::Pos qa = la.pos(prob, clampc(c + 2));
+            const typename LB::Pos qb = lb.pos(prob, clampc(c + 2));
             float a[2][MI][4], b[2][NI][4];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) TA::frag(sA, wm * 32 * MI + mi * 32 + l31, 0, h, a[0][mi]);
+            for (int mi = 0; mi < MI; ++mi) TA::frag(sA, (wm * MI + mi) * 32 + l31, 0, h, a[0][mi]);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) TB::frag(sB, wn * 32 * NI + ni * 32 + l31, 0, h, b[0][ni]);
+            for (int ni = 0; ni < NI; ++ni) TB::frag(sB, (wn * NI + ni) * 32 + l31, 0, h, b[0][ni]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int q = g >> 2, t = g & 3;
                 if (t == 0 && q < 3) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) TA::frag(sA, wm * 32 * MI + mi * 32 + l31, q + 1, h, a[(q + 1) & 1][mi]);
+                    for (int mi = 0; mi < MI; ++mi) TA::frag(sA, (wm * MI + mi) * 32 + l31, q + 1, h, a[(q + 1) & 1][mi]);
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) TB::frag(sB, wn * 32 * NI + ni * 32 + l31, q + 1, h, b[(q + 1) & 1][ni]);
+                    for (int ni = 0; ni < NI; ++ni) TB::frag(sB, (wn * NI + ni) * 32 + l31, q + 1, h, b[(q + 1) & 1][ni]);
+#ifdef CTX_PIN_FRAGS
+                    __builtin_amdgcn_sched_barrier(0);   // keep the prefetch above the MFMAs (A/B switch)
+#endif
                 }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi][t], b[q & 1][ni][t], acc[mi][ni], 0, 0, 0);
-                if (g < NA) la_[g] = fa.load1(la, prob, m0, c2, tid, g);
-                else if (g < NA + NB) lb_[g - NA] = fb.load1(lb, prob, n0, c2, tid, g - NA);
-                else if (g >= 8 && g - 8 < NA) TA::store(nA, tid, g - 8, sa_[g - 8]);
-                else if (g >= 8 && g - 8 < NA + NB) TB::store(nB, tid, g - 8 - NA, sb_[g - 8 - NA]);
+                const int s = g & 7;                       // slot index inside its half
+                const bool first_half = g < 8;
+                const bool do_load = TWO_SETS ? first_half : !first_half;
+                if (s < NA + NB) {
+                    if (do_load) {
+                        if (s < NA) la_[s] = fa.load1(la, qa, s);
+                        else lb_[s - NA] = fb.load1(lb, qb, s - NA);
+                    } else {
+                        if (s < NA) TA::store(nA, tid, s, sa_[s]);
+                        else TB::store(nB, tid, s - NA, sb_[s - NA]);
+                    }
+                }
             }
             __syncthreads();
         };
-        for (int c = cb; c < ce; c += 2) {
-            chunk(c, 0, ya, yb, xa, xb);
-            if (c + 1 < ce) chunk(c + 1, 1, xa, xb, ya, yb);
+        if (TWO_SETS) {
+            for (int c = cb; c < ce; c += 2) {
+                chunk(c, 0, ya, yb, xa, xb);
+                if (c + 1 < ce) chunk(c + 1, 1, xa, xb, ya, yb);
+            }
+        } else {
+            for (int c = cb; c < ce; ++c) chunk(c, (c - cb) & 1, xa, xb, xa, xb);
         }
     }
 
@@ -584,12 +725,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB l
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m >= M) continue;
             if (ep.slab) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int n = n0 + wn * 32 * NI + ni * 32 + l31;
+                    const int n = n0 + (wn * NI + ni) * 32 + l31;
                     if (n < N) ep.slab[(((int64_t)split * nprob + prob) * M + m) * N + n] = acc[mi][ni][r];
                 }
             } else {
@@ -597,7 +738,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const LA la, const LB l
                 if (!epi_row(ep, prob, m, pix)) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int n = n0 + wn * 32 * NI + ni * 32 + l31;
+                    const int n = n0 + (wn * NI + ni) * 32 + l31;
                     if (n < N) epi_store(ep, prob, pix, n, acc[mi][ni][r]);
                 }
             }

@@ -81,7 +81,7 @@ __device__ __forceinline__ float prep_u8(uint8_t x) {
 __global__ __launch_bounds__(NTHREADS) void u8_to_f32_kernel(const uint8_t* __restrict__ in, float* __restrict__ out,
                                                              int64_t n, int64_t in_period) {
     // 4 elements per thread; in_period: input repeats with this period (row broadcast), multiple of 4
-    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NTHREADS * 4) {
+    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 256 * 4) {
         const uchar4 u = *reinterpret_cast<const uchar4*>(in + (i % in_period));
         *reinterpret_cast<float4*>(out + i) = make_float4(prep_u8(u.x), prep_u8(u.y), prep_u8(u.z), prep_u8(u.w));
     }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(NTHREADS) void loss_partial_kernel(const float* __r
                                                                 float* __restrict__ dsim2, int64_t nz, float csim,
                                                                 float* __restrict__ partial) {
     __shared__ float sh[4];
-    const int64_t stride = (int64_t)gridDim.x * NTHREADS * 4;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     const int64_t start = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int64_t i = start; i < half; i += stride) {
@@ -276,7 +276,7 @@ void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, 
 // lrelu' on the saved output: d/dx max(x, 0.2x) = 1 for x >= 0 else 0.2; sign(y) == sign(x)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS) void lrelu_mask_kernel(float* __restrict__ g, const float* __restrict__ act, int64_t n) {
-    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NTHREADS * 4) {
+    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 256 * 4) {
         float4 v = ldg4(g + i);
         const float4 a = ldg4(act + i);
         v.x *= a.x >= 0.f ? 1.f : LEAK; v.y *= a.y >= 0.f ? 1.f : LEAK;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NTHREADS) void adam_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
                                                         float eps) {
     const float c1 = 1.f - b1, c2 = 1.f - b2;
-    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * NTHREADS * 4) {
+    for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 256 * 4) {
         const float4 gg = ldg4(g + i);
         float4 mm = ldg4(m + i), vv = ldg4(v + i), pp = ldg4(p + i);
 #define CTX_ADAM1(f)                                   \

@@ -20,11 +20,14 @@ struct SplitWs {
 void gemm_fc_fwd(hipStream_t s, const KmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
 void gemm_fc_dx(hipStream_t s, const KmPlain& a, const KmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
 void gemm_fc_dw(hipStream_t s, const NmPlain& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
+void gemm_fc_dw2(hipStream_t s, const NmPlain2& a, const NmPlain& b, Epi ep, int M, int N, int nchunks, SplitWs ws);
 void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b, Epi ep, int M, int N, SplitWs ws);
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws);
+void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
+void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws);
 
 // conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
 // product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a

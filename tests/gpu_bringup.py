@@ -52,6 +52,10 @@ def main(H=32, W=32, d=32, F=128, B=4, stddev=0.05):
     for name in ["img", "s0", "s1", "s2", "s3", "s4", "c0", "c1", "c2", "c3", "c4", "cz", "Z", "th0", "dz", "e1", "e2", "e3", "out"]:
         got = tr.debug_read(name, ref[name].size)
         e = rel(got, ref[name])
+        flips = int(np.count_nonzero((got >= 0) != (ref[name].ravel() >= 0)))   # lrelu' mask disagreements
+        if flips:
+            tiny = np.abs(ref[name].ravel()[(got >= 0) != (ref[name].ravel() >= 0)]).max() / np.abs(ref[name]).max()
+            print(f"      {name}: {flips} elements change sign between f32 HIP and f64 oracle (largest |x|/max = {tiny:.1e})")
         bad += e > 1e-4
         print(f"  fwd {name:4s} {str(ref[name].shape):22s} rel_err {e:.3e} {'' if e <= 1e-4 else '<<<<<<'}")
     # backward through the phase API on a plain hipMalloc'd copy of the inputs via train_step with lr=0
