@@ -454,7 +454,11 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(s, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws); }
             { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws); }
         } else {
-            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl); conv_wgrad2(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
+              if (patch_ok(hs, wsm)) {
+                  const PatchGeo pg = make_patch(2 * B, hs, wsm);
+                  conv_wgrad2_p(s, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws);
+              } else conv_wgrad2(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
               conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
         }
@@ -509,7 +513,11 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws);
                 break;   // no gradient w.r.t. the frame
             }
-            { ProfScope ps(h, ln + " dw", K_WGRAD, fl); conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
+            { ProfScope ps(h, ln + " dw", K_WGRAD, fl);
+              if (patch_ok(hs, wsm)) {
+                  const PatchGeo pg = make_patch(nimg, hs, wsm);
+                  conv_wgrad_p(s, NmWgradBigP{xin, ca, ca, wb, pg, g_zeros}, NmWgradSmallP{dA[k], cb, cb, pg, g_zeros}, eg, ca, cb, ws);
+              } else conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
             // input gradient = conv2d_transpose of dA[k] with the same filter read as [5,5,ca,cb]
             Epi ed;
             ed.out1 = dA[k - 1]; ed.ld1 = ca; ed.mask = act[k - 1]; ed.ldm = ca;

@@ -1,5 +1,6 @@
 // gemm_launch.h -- tile-shape dispatch and split-K policy for igemm_kernel (included by gemm_*.hip)
 #pragma once
+#include <cmath>
 #include <cstdlib>
 
 #include "launch.h"
@@ -23,9 +24,6 @@ static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, 
     hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 
-// Blocks wanted before the K loop is split: 256 CUs x ~3 resident blocks.
-constexpr int64_t TARGET_BLOCKS = 768;
-
 // BIG = the 8-wave 256x256 tile is instantiated for this loader pair
 template <class LA, class LB, bool BIG = false>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
@@ -39,17 +37,27 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
             return;
         }
     }
+    // (a 256x64 tile of four 64x64 waves for N <= 64 was measured: 1 block/CU, -15..-25 % vs 128x64; not kept)
     const int MI = M > 64 ? 2 : 1, NI = N > 64 ? 2 : 1;
     const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
+    // Split-K by a cost model, not a block-count target: a launch takes `rounds` passes over the resident
+    // slots (256 CUs x blocks/CU allowed by LDS), so 400 or 800 blocks on 512 slots run at 78 % -- the split
+    // count is chosen to minimise  rounds * (chunks per block + fixed cost)  + slab write/read time.
     int nsplit = 1;
-    if (tiles < TARGET_BLOCKS / 2 && min_chunks >= 8 && ws.slab) {
-        int64_t want = (TARGET_BLOCKS + tiles - 1) / tiles;
-        int64_t cap_k = min_chunks / 4;                                   // >= 4 chunks per split
-        int64_t cap_ws = ws.slab_floats / ((int64_t)nprob * M * N);
-        int64_t n = want < cap_k ? want : cap_k;
-        if (n > cap_ws) n = cap_ws;
-        if (n > 256) n = 256;
-        if (n > 1) nsplit = (int)n;
+    if (min_chunks >= 8 && ws.slab) {
+        const size_t lds = 2 * (size_t)((LA::KM ? 64 * MI * LDK : KC * 64 * MI) + (LB::KM ? 64 * NI * LDK : KC * 64 * NI)) * sizeof(float);
+        int occ = (int)(160 * 1024 / lds);
+        if (occ > (MI * NI == 4 ? 2 : 4)) occ = MI * NI == 4 ? 2 : 4;            // register-file limit
+        const double slots = 256.0 * occ;
+        const double t_chunk = 16.0 * MI * NI * 64.0 * occ / 2.3e9;             // `occ` waves share each SIMD's matrix pipe
+        const int64_t cap_ws = ws.slab_floats / ((int64_t)nprob * M * N);
+        double best = 1e30;
+        for (int n = 1; n <= 256 && n <= min_chunks / 4 && (n == 1 || n <= cap_ws); ++n) {
+            const double rounds = std::ceil(tiles * n / slots);
+            double t = rounds * ((min_chunks + n - 1) / n + 6) * t_chunk;
+            if (n > 1) t += 2.0 * n * nprob * (double)M * N * 4 / 3e12 + 4e-6;   // slab out + in, + the combine launch
+            if (t < best * 0.97) { best = t; nsplit = n; }                        // prefer fewer splits on near-ties
+        }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
     if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);

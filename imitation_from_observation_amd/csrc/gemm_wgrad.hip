@@ -5,6 +5,14 @@ void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi e
     ep.prob_stride = (int64_t)M * N;
     launch_igemm(s, a, b, ep, M, N, 25, (a.npix + KC - 1) / KC, ws);
 }
+void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.prob_stride = (int64_t)M * N;
+    launch_igemm(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
+}
+void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.prob_stride = (int64_t)M * N;
+    launch_igemm(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
+}
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
     launch_igemm(s, a, b, ep, 80, N, 1, (a.npix + KC - 1) / KC, ws);

@@ -508,6 +508,107 @@ struct NmWgradSmall2 {
     }
 };
 
+// ---- power-of-two grids: the filter gradient's K axis re-tiled into 32-pixel PATCHES ---------------
+// K (the pixel sum) may be walked in any order.  With hs, ws powers of two a chunk is a patch of R
+// stacked rows x C columns (C = min(ws, 32), R = 32 / C) of the image stack [imgs*hs, ws]; lane kk owns
+// (di, dj) = (kk / C, kk % C) for the whole kernel, the patch origin (rr0, j0) is wave-uniform.  Because
+// hb = 2 hs, row rr of the small stack meets rows 2 rr + ky - 1 of the big stack, so both operands are
+// "uniform base + invariant per-lane offset"; only the image-border validity depends on the chunk.
+struct PatchGeo {
+    int hs, ws, c_sh, C, R, ncol_sh, rows_total;   // ncol_sh = log2(ws / C)
+    __device__ __forceinline__ void origin(int chunk, int& rr0, int& j0) const {
+        rr0 = (chunk >> ncol_sh) * R;
+        j0 = (chunk & ((1 << ncol_sh) - 1)) << c_sh;
+    }
+    __device__ __forceinline__ int nchunks() const { return ((rows_total + R - 1) / R) << ncol_sh; }
+};
+inline bool patch_ok(int hs, int ws) { auto p2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; }; return p2(hs) && p2(ws); }
+inline PatchGeo make_patch(int nimg, int hs, int ws) {
+    auto lg = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
+    const int C = ws < 32 ? ws : 32;
+    return PatchGeo{hs, ws, lg(C), C, 32 / C, lg(ws / C), nimg * hs};
+}
+
+struct NmWgradBigP {
+    static constexpr bool KM = false;
+    const float* big; int64_t ldb; int ca;
+    int wb;
+    PatchGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t rs; int i0, j0, rows_left; bool top, bot, lef, rig; };
+    struct Ctx { int di, dj; uint32_t v; };
+    __device__ int nchunks_of(int) const { return g.nchunks(); }
+    __device__ Pos pos(int prob, int chunk) const {
+        const int ky = prob / 5, kx = prob - ky * 5;
+        int rr0, j0;
+        g.origin(chunk, rr0, j0);
+        const float* base = big + ((int64_t)(2 * rr0 + ky - 1) * wb + (2 * j0 + kx - 1)) * ldb;
+        return Pos{make_rsrc(base), rr0 & (g.hs - 1), j0, g.rows_total - rr0, ky == 0, ky >= 3, kx == 0, kx >= 3};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.di = kk >> g.c_sh; c.dj = kk & (g.C - 1);
+        c.v = r4 < ca ? (uint32_t)(((2 * c.di) * wb + 2 * c.dj) * (int)ldb + r4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const int i = (q.i0 + c.di) & (g.hs - 1), j = q.j0 + c.dj;
+        // y = 2i+ky-1 in [0, 2hs): fails for (i == 0, ky == 0) and (i == hs-1, ky >= 3); same in x
+        const bool bad = c.di >= q.rows_left || (q.top && i == 0) || (q.bot && i == g.hs - 1) || (q.lef && j == 0) ||
+                         (q.rig && j == g.ws - 1);
+        return bload4(q.rs, bad ? OOB : c.v);
+    }
+};
+
+struct NmWgradSmallP {
+    static constexpr bool KM = false;
+    const float* s1; int64_t ld1; int cb;
+    PatchGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t rs; int rows_left; };
+    struct Ctx { int di; uint32_t v; };
+    __device__ Pos pos(int, int chunk) const {
+        int rr0, j0;
+        g.origin(chunk, rr0, j0);
+        return Pos{make_rsrc(s1 + ((int64_t)rr0 * g.ws + j0) * ld1), g.rows_total - rr0};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.di = kk >> g.c_sh;
+        const int dj = kk & (g.C - 1);
+        c.v = r4 < cb ? (uint32_t)((c.di * g.ws + dj) * (int)ld1 + r4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.di < q.rows_left ? c.v : OOB); }
+};
+
+struct NmWgradSmall2P {
+    static constexpr bool KM = false;
+    const float* s1; int64_t ld1; int c1;
+    const float* s2; int64_t ld2; int nmod2;     // s2 = ctx skip, stacked rows wrap at nmod2 * hs
+    int cb;
+    PatchGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t r1, r2; int rr0, pix0, rows_left; };
+    struct Ctx { int di, pix; uint32_t v1, r2; };
+    __device__ Pos pos(int, int chunk) const {
+        int rr0, j0;
+        g.origin(chunk, rr0, j0);
+        const int pix0 = rr0 * g.ws + j0;
+        return Pos{make_rsrc(s1 + (int64_t)pix0 * ld1), make_rsrc(s2), rr0, pix0, g.rows_total - rr0};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.di = kk >> g.c_sh;
+        c.pix = c.di * g.ws + (kk & (g.C - 1));
+        c.v1 = r4 < c1 ? (uint32_t)(c.pix * (int)ld1 + r4) * 4u : OOB;
+        c.r2 = (r4 >= c1 && r4 < cb) ? (uint32_t)(r4 - c1) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const bool ok = c.di < q.rows_left;
+        const int wrap_rows = nmod2 * g.hs;
+        const int pix2 = q.pix0 + c.pix - (q.rr0 + c.di >= wrap_rows ? wrap_rows * g.ws : 0);
+        const float4 a = bload4(q.r1, ok ? c.v1 : OOB);
+        const float4 b = bload4(q.r2, ok ? (uint32_t)(pix2 * (int)ld2) * 4u + c.r2 : OOB);
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+};
+
 // Filter gradient when the big tensor has 3 channels: rows m = ky*16 + el (el = kx*3+ch < 15).
 struct NmC3WgradBig {
     static constexpr bool KM = false;
@@ -598,10 +699,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     using TA = Tile<LA::KM, TM, NT>;
     using TB = Tile<LB::KM, TN, NT>;
     constexpr int NA = TA::NPASS, NB = TB::NPASS;       // float4 per thread per chunk
-    static_assert(NA + NB <= 8, "one load and one store slot per MFMA group");
+    static_assert(NA + NB <= 16, "at most one load and one store per MFMA group");
     constexpr int STAGE = TA::FLOATS + TB::FLOATS;
     // two register sets (1.5-chunk prefetch distance) only where the register file has room
     constexpr bool TWO_SETS = MI * NI <= 4;
+    static_assert(TWO_SETS || NA + NB <= 8, "single register set: stores then loads must fit 16 groups");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 stages of [A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -613,7 +715,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     int rest = blockIdx.x;
     const int bx = rest % gm; rest /= gm;
     const int by = rest % gn; rest /= gn;
-    const int prob = nprob - 1 - rest % nprob;
+    // transposed conv (nprob == 4): parity classes have 4/6/6/9 taps.  Dispatching 9,6,4,6 makes the two
+    // blocks that share a CU (one from each half of a 2-per-CU round) sum to 13 and 12 taps, not 15 and 10.
+    const int pr = rest % nprob;
+    const int prob = nprob == 4 ? ((0x3201 >> (4 * (3 - pr))) & 15) : nprob - 1 - pr;
     const int split = rest / nprob;
     const int m0 = bx * TM, n0 = by * TN;
 
@@ -695,17 +800,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q & 1][mi][t], b[q & 1][ni][t], acc[mi][ni], 0, 0, 0);
-                const int s = g & 7;                       // slot index inside its half
-                const bool first_half = g < 8;
-                const bool do_load = TWO_SETS ? first_half : !first_half;
-                if (s < NA + NB) {
-                    if (do_load) {
-                        if (s < NA) la_[s] = fa.load1(la, qa, s);
-                        else lb_[s - NA] = fb.load1(lb, qb, s - NA);
-                    } else {
-                        if (s < NA) TA::store(nA, tid, s, sa_[s]);
-                        else TB::store(nB, tid, s - NA, sb_[s - NA]);
-                    }
+                // gap after group g.  Two sets: loads (into the free set) in groups [0, NA+NB), stores (of the
+                // other set) in groups [16-NA-NB, 16) -- they may overlap.  One set: stores first, then reloads.
+                constexpr int NLS = NA + NB;
+                const int ld = TWO_SETS ? g : g - 8, st_ = TWO_SETS ? g - (16 - NLS) : g;
+                if (ld >= 0 && ld < NLS) {
+                    if (ld < NA) la_[ld] = fa.load1(la, qa, ld);
+                    else lb_[ld - NA] = fb.load1(lb, qb, ld - NA);
+                }
+                if (st_ >= 0 && st_ < NLS) {
+                    if (st_ < NA) TA::store(nA, tid, st_, sa_[st_]);
+                    else TB::store(nB, tid, st_ - NA, sb_[st_ - NA]);
                 }
             }
             __syncthreads();

@@ -25,6 +25,9 @@ void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b, Epi ep, in
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws);
+// power-of-two grids: patch-ordered K (see igemm.h PatchGeo)
+void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws);
+void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws);
