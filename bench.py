@@ -131,6 +131,17 @@ def main():
                             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "launches_per_step": k["launches"],
                             "avg_ms_per_launch": per_launch_ms, "flops_per_launch": k["flops"] / k["launches"],
                             "share_of_step_ms": k["ms"] / sum(t["ms"] for t in tab.values()), "traffic": None}
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
+        # figure comes from the committed rocprofv3 --pmc passes of the same workload (profiles/*_hbm_traffic.json)
+        import glob
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+        if prof and B == 256:
+            with open(prof[-1]) as f:
+                tr_json = json.load(f)
+            ent = tr_json["per_kernel"].get(kname)
+            if ent:
+                line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_source"] = os.path.basename(prof[-1])
         line["kernels"] = {n: {"ms": round(t["ms"], 4), "launches": t["launches"],
                                "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None}
                            for n, t in tab.items()}

@@ -72,7 +72,13 @@ class DataParallelTrainer:
         self.world = _world()
         self.n_params = self.engine.n_params
         if self.world > 1:
-            dist.broadcast(self.engine.params, src=0)       # replicas start identical
+            # replicas start identical.  Issued on the engine's stream (the collective orders itself after the
+            # current stream) and drained, so the first forward cannot race the incoming parameters.
+            stream = getattr(self.engine, "stream", None)
+            with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                dist.broadcast(self.engine.params, src=0)
+            if stream is not None:
+                stream.synchronize()
         self.translator = getattr(self.engine, "translator", None)
 
     def step(self, src, ctx, tgt, lr=1e-4):
