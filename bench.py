@@ -45,8 +45,17 @@ def cpu_baseline(batch, steps):
     for t in range(2, 2 + steps):
         o.train_step(p, m, v, t, src, ctx, tgt, 1e-4, cfg)
     dt = time.perf_counter() - t0
-    return {"value": batch * steps / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s"}
+    threads = os.cpu_count()
+    try:                                     # the threads numpy's BLAS actually runs the matmuls on
+        from threadpoolctl import threadpool_info
+        blas = [t["num_threads"] for t in threadpool_info() if t.get("user_api") == "blas"]
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    return {"value": batch * steps / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s, "
+                      f"BLAS threads {threads} of {os.cpu_count()} logical CPUs (im2col/col2im parts are single-threaded)"}
 
 
 def main():

@@ -54,6 +54,8 @@ SIGNATURES = {
     "ctx_encode": (_c.c_int, [_P, _U8, _c.c_int, _F, _F]),
     "ctx_train_step": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _c.c_float, _F]),
     "ctx_train_step_u8": (_c.c_int, [_P, _U8, _U8, _U8, _c.c_int, _c.c_float, _F]),
+    "ctx_demos_upload": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),
+    "ctx_train_step_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _c.c_float, _F]),
     "ctx_eval": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _F, _F, _F]),
     "ctx_dev_forward_backward": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int]),
     "ctx_dev_forward": (_c.c_int, [_P, _P, _P, _P, _c.c_int]),

@@ -74,6 +74,11 @@ struct ctx_handle {
     float *dth0 = nullptr, *dcz = nullptr, *dS[5] = {}, *dC[5] = {};
     float *scratch = nullptr, *slab = nullptr, *scalars = nullptr;
     float* zeros = nullptr;   // 256 B of zeros for the branch-free loaders
+    // resident demo tensor (ctx_demos_upload): uint8 vdata[T][N][H*W*3], the x/127.5-1 table, index staging
+    uint8_t* vdata = nullptr;
+    int vT = 0, vN = 0;
+    float* lut = nullptr;
+    int* choice = nullptr;    // [2 * max_batch]: choicesrc | choicetgt
     float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
     int64_t slab_floats = 0;
 
@@ -654,6 +659,7 @@ void ctx_destroy(ctx_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    if (h->vdata) (void)hipFree(h->vdata);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -902,6 +908,43 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
         entries[i].ms = (float)(h->prof_ms[i] / iters);
     }
     return CTX_OK;
+}
+
+int ctx_demos_upload(ctx_handle* h, const uint8_t* vdata, int T, int N) {
+    if (!h || !vdata || T <= 0 || N <= 0) return h ? fail(h, CTX_E_INVALID, "bad demo tensor") : CTX_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->vdata) { (void)hipFree(h->vdata); h->vdata = nullptr; }
+    const size_t bytes = (size_t)T * N * h->npi;
+    if (hipMalloc((void**)&h->vdata, bytes) != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%zu bytes) for the demo tensor", bytes);
+    if (!h->lut) {
+        TRY(dev_alloc(h, &h->lut, 256));
+        TRY(dev_alloc(h, &h->choice, 2 * (int64_t)h->Bm));
+        float host[256];
+        for (int i = 0; i < 256; ++i) host[i] = (float)((double)i / 127.5 - 1.0);   // train_script.py:16-19, then the f32 feed
+        HIP_TRY(h, hipMemcpy(h->lut, host, sizeof host, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->vdata, vdata, bytes, hipMemcpyHostToDevice, h->stream));
+    h->vT = T; h->vN = N;
+    return finish(h);
+}
+
+int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B, float lr, float scalars[4]) {
+    TRY(check_B(h, B));
+    if (!h->vdata) return fail(h, CTX_E_STATE, "ctx_demos_upload first");
+    if (!choicesrc || !choicetgt) return fail(h, CTX_E_INVALID, "NULL index array");
+    for (int b = 0; b < B; ++b)
+        if (choicesrc[b] < 0 || choicesrc[b] >= h->vN || choicetgt[b] < 0 || choicetgt[b] >= h->vN)
+            return fail(h, CTX_E_INVALID, "video index out of range [0,%d)", h->vN);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
+    forward(h, B, MODE_TRAIN);
+    backward(h, B, B);
+    TRY(adam_step(h, lr));
+    h->last_B = B;
+    if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
 }
 
 // Test hook: copy an internal device buffer to the host (names: img Z dZ cz th0 dz out dout dDz dsim2

@@ -102,6 +102,37 @@ void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batch sampler on device (scripts/train_script.py:153-159): from the resident uint8 demo tensor
+// vdata[T][N][H*W*3] build img = [tgt | src | ctx]:
+//   src[b] = vdata[b % T][choicesrc[b]],  tgt[b] = vdata[b % T][choicetgt[b]],  ctx[b] = vdata[0][choicetgt[b]]
+// with the trainer's scaling x / 127.5 - 1 (train_script.py:16-19) applied through a 256-entry table that
+// the host computed in float64 and rounded once to f32 -- bit-identical to feeding the numpy-scaled frames.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void gather_triples_kernel(const uint8_t* __restrict__ vdata, int T, int N, int64_t npi,
+                                                                  const int* __restrict__ csrc, const int* __restrict__ ctgt,
+                                                                  int B, const float* __restrict__ lut, float* __restrict__ img) {
+    __shared__ float sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int64_t per = npi / 4, total = 3 * (int64_t)B * per;
+    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
+        const int64_t e4 = idx % per;
+        const int64_t r = idx / per;
+        const int b = (int)(r % B), slot = (int)(r / B);          // slot 0 tgt, 1 src, 2 ctx
+        const int t = slot == 2 ? 0 : b % T;
+        const int v = slot == 1 ? csrc[b] : ctgt[b];
+        const uchar4 u = *reinterpret_cast<const uchar4*>(vdata + ((int64_t)t * N + v) * npi + e4 * 4);
+        *reinterpret_cast<float4*>(img + r * npi + e4 * 4) = make_float4(sl[u.x], sl[u.y], sl[u.z], sl[u.w]);
+    }
+}
+
+void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B,
+                    const float* lut, float* img) {
+    hipLaunchKernelGGL(gather_triples_kernel, dim3(ew_blocks(3 * (int64_t)B * npi / 4)), dim3(NTHREADS), 0, s, vdata, T, N, npi,
+                       csrc, ctgt, B, lut, img);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Losses.  recon_k = tf.nn.l2_loss(tgt - out_k) = sum(d^2)/2 over the WHOLE batch
 // (arm_shaping.py:1352-1353); simloss = mean((trans_z - tgtimg_z)^2) * 1e3 (:1345).
 // Wavefront shuffle reduction -> one partial per block -> fixed-order final sum in f64.

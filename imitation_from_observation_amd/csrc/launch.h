@@ -44,6 +44,10 @@ void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
 // out[r] = in[r % nrows_in] -- the [context]*batch_size broadcast of base.py:217-218
 void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows);
 
+// device batch sampler (scripts/train_script.py:153-159); lut[256] = f32(x / 127.5 - 1)
+void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B,
+                    const float* lut, float* img);
+
 // Losses (arm_shaping.py:1345,1352-1354) and their seeds of the backward pass.
 //   out [2B, npi] (rows < B: translated pass, rows >= B: truth pass), tgt [B, npi]
 //   dout (nullable) = out - tgt[n % B]

@@ -223,6 +223,26 @@ class Translator:
         self._ck(self._lib.ctx_train_step_u8(self._h, _up(src), _up(ctx), _up(tgt), shp[0], float(lr), _fp(sc)))
         return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
+    def load_demos(self, vdata_u8):
+        """Keep the demo tensor vdata[T,N,H,W,3] (uint8) resident on the device (train_script.py:59-96 builds it)."""
+        v = _u8(vdata_u8)
+        if v.ndim != 5 or v.shape[2:] != (self.H, self.W, 3):
+            raise ValueError(f"vdata must be [T,N,{self.H},{self.W},3], got {v.shape}")
+        self._ck(self._lib.ctx_demos_upload(self._h, _up(v), v.shape[0], v.shape[1]))
+        self.demo_shape = v.shape[:2]
+
+    def train_step_sampled(self, choicesrc, choicetgt, lr=1e-4):
+        """One train step on the batch the reference samples from `traindata` (train_script.py:153-163):
+        choicesrc / choicetgt = np.random.choice(ntrain, batch_size)."""
+        cs = np.ascontiguousarray(choicesrc, dtype=np.int32)
+        ct = np.ascontiguousarray(choicetgt, dtype=np.int32)
+        if cs.shape != ct.shape or cs.ndim != 1:
+            raise ValueError("choicesrc / choicetgt must be 1-D and equally long")
+        sc = np.empty(4, np.float32)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._ck(self._lib.ctx_train_step_sampled(self._h, cs.ctypes.data_as(ip), ct.ctypes.data_as(ip), cs.size, float(lr), _fp(sc)))
+        return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
     def evaluate(self, src, ctx, tgt, outputs=True):
         """Forward + losses (train_script.py:176,192-193)."""
         src, ctx, tgt, B = self._triple(src, ctx, tgt)

@@ -115,6 +115,14 @@ int ctx_train_step(ctx_handle* h, const float* src, const float* ctx, const floa
 /* Same on uint8 frames, preprocessed on device with (x/255 - 0.5)*2. */
 int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx, const uint8_t* tgt,
                       int B, float lr, float scalars[4]);
+/* The trainer's input pipeline on device (scripts/train_script.py:144-159).  ctx_demos_upload keeps the demo
+ * tensor vdata[T][N][H][W][3] (uint8 frames, T frames of N videos) resident in HBM; ctx_train_step_sampled
+ * builds the batch  src[b] = vdata[b % T][choicesrc[b]], tgt[b] = vdata[b % T][choicetgt[b]],
+ * ctx[b] = vdata[0][choicetgt[b]]  with the trainer's x/127.5 - 1 scaling and runs one train step.  The two
+ * index arrays are what `np.random.choice(ntrain, batch_size)` returns (:154-155). */
+int ctx_demos_upload(ctx_handle* h, const uint8_t* vdata, int T, int N);
+int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B,
+                           float lr, float scalars[4]);
 /* Forward + losses only.  out / out2 (nullable) [B,H,W,3]. */
 int ctx_eval(ctx_handle* h, const float* src, const float* ctx, const float* tgt, int B,
              float scalars[4], float* out, float* out2);

@@ -264,6 +264,35 @@ def test_error_behaviour(T):
             tr.set_params_flat(np.zeros(5, np.float32))
 
 
+def test_device_batch_sampler_equals_host_gather(T):
+    """ctx_train_step_sampled (resident demo tensor + device gather) == the reference's host-side batch
+    (scripts/train_script.py:153-159, transform :16-19) fed through ctx_train_step."""
+    H, W, d, F, B = 16, 16, 32, 32, 7
+    Tn, N = 5, 11                                               # nlen frames, N videos
+    rng = np.random.default_rng(21)
+    vdata_u8 = rng.integers(0, 256, (Tn, N, H, W, 3), dtype=np.uint8)
+    traindata = vdata_u8 / 127.5 - 1.0                           # float64, as transform() makes it
+    cfg, p, _ = make_case(H, W, d, F, B, seed=22, dtype=np.float32)
+    with T(H, W, d, F, max_batch=B) as a, T(H, W, d, F, max_batch=B) as b:
+        a.set_params(p)
+        b.set_params(p)
+        a.load_demos(vdata_u8)
+        for _ in range(2):
+            choicesrc, choicetgt = rng.choice(N, B), rng.choice(N, B)
+            srcdata = traindata[np.arange(0, B) % Tn, choicesrc]
+            tgtdata = traindata[np.arange(0, B) % Tn, choicetgt]
+            tgtctx = traindata[0, choicetgt]
+            sa = a.train_step_sampled(choicesrc, choicetgt, lr=1e-3)
+            sb = b.train_step(srcdata, tgtctx, tgtdata, lr=1e-3)       # float64 -> f32 at the feed, like TF
+            assert sa == sb
+        np.testing.assert_array_equal(a.get_params_flat(), b.get_params_flat())
+        from imitation_from_observation_amd import CtxError
+        with pytest.raises(CtxError):
+            a.train_step_sampled(np.full(B, N), np.zeros(B, int))   # index out of range
+        with pytest.raises(CtxError):
+            b.train_step_sampled(choicesrc, choicetgt)               # no demo tensor uploaded
+
+
 def test_device_phase_api_equals_host_api(T):
     """ctx_dev_forward_backward + ctx_dev_adam on torch-owned memory/stream (the bench / DP path)
     == ctx_train_step."""
