@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <string>
@@ -74,6 +75,13 @@ struct ctx_handle {
     float *dth0 = nullptr, *dcz = nullptr, *dS[5] = {}, *dC[5] = {};
     float *scratch = nullptr, *slab = nullptr, *scalars = nullptr;
     float* zeros = nullptr;   // 256 B of zeros for the branch-free loaders
+    // second lane: the conv_context encoder (forward and backward) is independent of the `conv` encoder chain
+    // and runs on its own stream with its own split-K slab / reduction scratch, so its half-size launches fill
+    // the tails of the other chain's launches
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *slab2 = nullptr, *scratch2 = nullptr;
+    bool overlap = true;
     // resident demo tensor (ctx_demos_upload): uint8 vdata[T][N][H*W*3], the x/127.5-1 table, index staging
     uint8_t* vdata = nullptr;
     int vT = 0, vN = 0;
@@ -262,6 +270,8 @@ int alloc_buffers(ctx_handle* h) {
     TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
     h->slab_floats = 32ll << 20;
     TRY(dev_alloc(h, &h->slab, h->slab_floats));
+    TRY(dev_alloc(h, &h->slab2, h->slab_floats));
+    TRY(dev_alloc(h, &h->scratch2, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
     TRY(dev_alloc(h, &h->scalars, 4));
     TRY(dev_alloc(h, &h->zeros, 64));
     if (hipMemset(h->zeros, 0, 64 * sizeof(float)) != hipSuccess) return fail(h, CTX_E_DEVICE, "hipMemset(zeros)");
@@ -269,6 +279,22 @@ int alloc_buffers(ctx_handle* h) {
 }
 
 SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats}; }
+
+// Everything below enqueues on h->stream with h->slab / h->scratch; LaneSwap points those at the second lane
+// for the lifetime of a scope.  fork(): the second lane starts after everything enqueued so far on the
+// main stream; join(): the main stream continues after everything enqueued so far on the second lane.
+struct LaneSwap {
+    ctx_handle* h;
+    hipStream_t s0;
+    float *sl0, *sc0;
+    explicit LaneSwap(ctx_handle* h_) : h(h_), s0(h_->stream), sl0(h_->slab), sc0(h_->scratch) {
+        h->stream = h->aux; h->slab = h->slab2; h->scratch = h->scratch2;
+    }
+    ~LaneSwap() { h->stream = s0; h->slab = sl0; h->scratch = sc0; }
+};
+bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux && !h->prof_on; }
+void fork(ctx_handle* h) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0); }
+void join(ctx_handle* h) { (void)hipEventRecord(h->ev_join, h->aux); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); }
 
 const char* const K_CONV = "igemm<ConvGather,Plain>";
 const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
@@ -380,10 +406,17 @@ void forward(ctx_handle* h, int B, Mode mode) {
     const int64_t npi = h->npi;
     const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
     float* src_z = h->Z + 2ll * B * F;
+    const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
+    if (lanes) {
+        fork(h);
+        LaneSwap sw(h);
+        encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+    }
     if (mode == MODE_TRAIN) encoder_fwd(h, "conv", st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
     else encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
     if (mode == MODE_ENCODE) return;
-    encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+    if (lanes) join(h);
+    else encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
     // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
     KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC, g_zeros};
     fc_layer(h, "translate/trans_h0", tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
@@ -425,13 +458,11 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
-    hipStream_t s = h->stream;
-    const SplitWs ws = ws_of(h);
     float* tgt_z = h->Z + (int64_t)B * F;
     float* src_z = h->Z + 2ll * B * F;
     {
         ProfScope ps(h, "losses", K_EW, 0.0);
-        losses(s, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+        losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
     }
 
     // ---- decoder, both passes at once (batch 2B)
@@ -456,16 +487,16 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
         if (ca == 3) {
-            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(s, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws); }
-            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(s, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws); }
+            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(h->stream, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
         } else {
             { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
               if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(2 * B, hs, wsm);
-                  conv_wgrad2_p(s, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws);
-              } else conv_wgrad2(s, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
+                  conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
+              } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
-              conv_fwd(s, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws); }
+              conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
         }
         dy = d_dec;
     }
@@ -515,14 +546,14 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
             if (k == 0) {
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
-                conv3_wgrad(s, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws);
+                conv3_wgrad(h->stream, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 break;   // no gradient w.r.t. the frame
             }
             { ProfScope ps(h, ln + " dw", K_WGRAD, fl);
               if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(nimg, hs, wsm);
-                  conv_wgrad_p(s, NmWgradBigP{xin, ca, ca, wb, pg, g_zeros}, NmWgradSmallP{dA[k], cb, cb, pg, g_zeros}, eg, ca, cb, ws);
-              } else conv_wgrad(s, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws); }
+                  conv_wgrad_p(h->stream, NmWgradBigP{xin, ca, ca, wb, pg, g_zeros}, NmWgradSmallP{dA[k], cb, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
+              } else conv_wgrad(h->stream, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
             // input gradient = conv2d_transpose of dA[k] with the same filter read as [5,5,ca,cb]
             Epi ed;
             ed.out1 = dA[k - 1]; ed.ld1 = ca; ed.mask = act[k - 1]; ed.ldm = ca;
@@ -531,17 +562,26 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
             ProfScope ps(h, ln + " dx", K_CONVT, fl);
-            convt_fwd(s, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
-                      ed, R, ca, ws);
+            convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
+                      ed, R, ca, ws_of(h));
         }
     };
     // `conv` on [tgt | src]: code gradients are rows [B, 3B) of dZ; hz_lin has an lrelu
     float* dSz = h->dZ + (int64_t)B * F;
-    { ProfScope ps(h, "conv/hz_lin lrelu'", K_EW, 0.0); lrelu_mask(s, dSz, tgt_z, 2ll * B * F); }
+    const bool lanes = use_lanes(h);
+    if (lanes) {
+        // `conv_context` (linear hz_lin; its h0..h3 also fed both decoder passes as skips) on the second lane:
+        // everything it reads (dcz, dSk[*], c[*]) was produced before this point
+        fork(h);
+        LaneSwap sw(h);
+        encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+    }
+    { ProfScope ps(h, "conv/hz_lin lrelu'", K_EW, 0.0); lrelu_mask(h->stream, dSz, tgt_z, 2ll * B * F); }
     encoder_bwd("conv", scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false);
-    // `conv_context`: linear hz_lin; its h0..h3 also feed both decoder passes as skips
-    encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+    if (lanes) join(h);
+    else encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
     h->have_grads = true;
+
 }
 
 int check_B(ctx_handle* h, int B) {
@@ -637,6 +677,14 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     }
     if (rc == CTX_OK) rc = alloc_buffers(h);
     if (rc == CTX_OK) {
+        const char* ov = getenv("CTX_OVERLAP");
+        h->overlap = !(ov && ov[0] == '0');
+        if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
+            rc = fail(h, CTX_E_DEVICE, "second-lane stream/event creation failed");
+    }
+    if (rc == CTX_OK) {
         e = hipMemsetAsync(h->arena + h->Ppad, 0, 3 * h->Ppad * sizeof(float), h->stream);   // grads, m, v
         if (e == hipSuccess && h->own_arena) e = hipMemsetAsync(h->arena, 0, h->Ppad * sizeof(float), h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -660,6 +708,9 @@ void ctx_destroy(ctx_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
+    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
