@@ -78,9 +78,12 @@ struct ctx_handle {
     // second lane: the conv_context encoder (forward and backward) is independent of the `conv` encoder chain
     // and runs on its own stream with its own split-K slab / reduction scratch, so its half-size launches fill
     // the tails of the other chain's launches
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    float *slab2 = nullptr, *scratch2 = nullptr;
+    // lane 0 = conv_context chain; lane 1 = filter / bias gradients (off the backward critical path: only the
+    // input gradients feed the next layer)
+    static constexpr int NLANE = 2;
+    hipStream_t aux[NLANE] = {};
+    hipEvent_t ev_fork[NLANE] = {}, ev_join[NLANE] = {};
+    float *slabL[NLANE] = {}, *scratchL[NLANE] = {};
     bool overlap = true;
     // resident demo tensor (ctx_demos_upload): uint8 vdata[T][N][H*W*3], the x/127.5-1 table, index staging
     uint8_t* vdata = nullptr;
@@ -270,8 +273,10 @@ int alloc_buffers(ctx_handle* h) {
     TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
     h->slab_floats = 32ll << 20;
     TRY(dev_alloc(h, &h->slab, h->slab_floats));
-    TRY(dev_alloc(h, &h->slab2, h->slab_floats));
-    TRY(dev_alloc(h, &h->scratch2, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
+    for (int l = 0; l < ctx_handle::NLANE; ++l) {
+        TRY(dev_alloc(h, &h->slabL[l], h->slab_floats));
+        TRY(dev_alloc(h, &h->scratchL[l], std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
+    }
     TRY(dev_alloc(h, &h->scalars, 4));
     TRY(dev_alloc(h, &h->zeros, 64));
     if (hipMemset(h->zeros, 0, 64 * sizeof(float)) != hipSuccess) return fail(h, CTX_E_DEVICE, "hipMemset(zeros)");
@@ -287,14 +292,38 @@ struct LaneSwap {
     ctx_handle* h;
     hipStream_t s0;
     float *sl0, *sc0;
-    explicit LaneSwap(ctx_handle* h_) : h(h_), s0(h_->stream), sl0(h_->slab), sc0(h_->scratch) {
-        h->stream = h->aux; h->slab = h->slab2; h->scratch = h->scratch2;
+    LaneSwap(ctx_handle* h_, int lane) : h(h_), s0(h_->stream), sl0(h_->slab), sc0(h_->scratch) {
+        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane];
     }
     ~LaneSwap() { h->stream = s0; h->slab = sl0; h->scratch = sc0; }
 };
-bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux && !h->prof_on; }
-void fork(ctx_handle* h) { (void)hipEventRecord(h->ev_fork, h->stream); (void)hipStreamWaitEvent(h->aux, h->ev_fork, 0); }
-void join(ctx_handle* h) { (void)hipEventRecord(h->ev_join, h->aux); (void)hipStreamWaitEvent(h->stream, h->ev_join, 0); }
+bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux[0] && !h->prof_on; }
+// fork: `lane` starts after everything enqueued so far on the CURRENT stream; join: the current stream
+// continues after everything enqueued so far on `lane`
+void fork(ctx_handle* h, int lane) {
+    (void)hipEventRecord(h->ev_fork[lane], h->stream);
+    (void)hipStreamWaitEvent(h->aux[lane], h->ev_fork[lane], 0);
+}
+void join(ctx_handle* h, int lane) {
+    (void)hipEventRecord(h->ev_join[lane], h->aux[lane]);
+    (void)hipStreamWaitEvent(h->stream, h->ev_join[lane], 0);
+}
+// Side(h, lane): run the enclosed launches on `lane`, ordered after what the current stream has queued;
+// a no-op (stays on the current stream) when lanes are off
+struct Side {
+    ctx_handle* h;
+    bool on;
+    hipStream_t s0 = nullptr;
+    float *sl0 = nullptr, *sc0 = nullptr;
+    Side(ctx_handle* h_, int lane) : h(h_), on(lane >= 0 && use_lanes(h_)) {
+        if (!on) return;
+        fork(h, lane);
+        s0 = h->stream; sl0 = h->slab; sc0 = h->scratch;
+        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane];
+    }
+    ~Side() { if (on) { h->stream = s0; h->slab = sl0; h->scratch = sc0; } }
+};
+constexpr int LANE_CTX = 0, LANE_DW = 1;
 
 const char* const K_CONV = "igemm<ConvGather,Plain>";
 const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
@@ -408,14 +437,14 @@ void forward(ctx_handle* h, int B, Mode mode) {
     float* src_z = h->Z + 2ll * B * F;
     const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
     if (lanes) {
-        fork(h);
-        LaneSwap sw(h);
+        fork(h, LANE_CTX);
+        LaneSwap sw(h, LANE_CTX);
         encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
     }
     if (mode == MODE_TRAIN) encoder_fwd(h, "conv", st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
     else encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
     if (mode == MODE_ENCODE) return;
-    if (lanes) join(h);
+    if (lanes) join(h, LANE_CTX);
     else encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
     // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
     KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC, g_zeros};
@@ -476,7 +505,6 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         const float* w = h->Wp((nm_ + "/w").c_str());
         const float* dec_in = k > 1 ? h->e[k - 1] : h->dz;      // decoder half of the concat input
         float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
-        bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
         const double fl = 2.0 * R * 25 * cb * ca;
         NmWgradSmall2 small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
         Epi eg;
@@ -487,10 +515,14 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
         if (ca == 3) {
-            { ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
+            { Side sd(h, LANE_DW);
+              bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
+              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
             { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(h->stream, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
         } else {
-            { ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
+            { Side sd(h, LANE_DW);
+              bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
+              ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
               if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(2 * B, hs, wsm);
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
@@ -503,32 +535,35 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     // d_h0_lin: input Z[0:2B] = [trans_z | tgt_z]; simloss adds +-c(trans_z - tgt_z) to its gradient
     {
         const int D0 = (int)h->D0;
-        fc_dw(h, "deconv/d_h0_lin", nm(h->Z, F, F, 2 * B), F, h->dDz, 2 * B, D0, h->Gp("deconv/d_h0_lin/Matrix"), h->Gp("deconv/d_h0_lin/bias"));
+        { Side sd(h, LANE_DW);
+          fc_dw(h, "deconv/d_h0_lin", nm(h->Z, F, F, 2 * B), F, h->dDz, 2 * B, D0, h->Gp("deconv/d_h0_lin/Matrix"), h->Gp("deconv/d_h0_lin/bias")); }
         Epi ep;
         ep.out1 = h->dZ; ep.ld1 = F; ep.add1 = h->dsim2; ep.lda1 = F;
         fc_dx(h, "deconv/d_h0_lin", h->dDz, 2 * B, D0, h->Wp("deconv/d_h0_lin/Matrix"), F, ep);
     }
     // ---- translate MLP: d trans_z = dZ[0:B]
     {
-        fc_dw(h, "translate/trans_z", nm(h->th0, F, F, B), F, h->dZ, B, F, h->Gp("translate/trans_z/Matrix"), h->Gp("translate/trans_z/bias"));
+        { Side sd(h, LANE_DW);
+          fc_dw(h, "translate/trans_z", nm(h->th0, F, F, B), F, h->dZ, B, F, h->Gp("translate/trans_z/Matrix"), h->Gp("translate/trans_z/bias")); }
         Epi e1;
         e1.out1 = h->dth0; e1.ld1 = F; e1.mask = h->th0; e1.ldm = F;
         fc_dx(h, "translate/trans_z", h->dZ, B, F, h->Wp("translate/trans_z/Matrix"), F, e1);
         NmPlain2 tcat{src_z, F, h->cz, F, F, 2 * F, B, g_zeros};
-        fc_dw(h, "translate/trans_h0", tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias"));
+        { Side sd(h, LANE_DW);
+          fc_dw(h, "translate/trans_h0", tcat, 2 * F, h->dth0, B, F, h->Gp("translate/trans_h0/Matrix"), h->Gp("translate/trans_h0/bias")); }
         Epi e2;   // d concat: cols < F -> d src_z (row block 2 of dZ), cols >= F -> d ctx_z
         e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;
         fc_dx(h, "translate/trans_h0", h->dth0, B, F, h->Wp("translate/trans_h0/Matrix"), 2 * F, e2);
     }
     // ---- encoders
     auto encoder_bwd = [&](const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* dzp, float* const dA[5],
-                           bool with_skips) {
+                           bool with_skips, int dw_lane) {
         const int K3 = h->hh[4] * h->ww[4] * 8 * d;
-        fc_dw(h, scn + "/hz_lin", nm(act[4], F, F, nimg), F, dzp, nimg, F, sc.gwz, sc.gbz);
+        { Side sd(h, dw_lane); fc_dw(h, scn + "/hz_lin", nm(act[4], F, F, nimg), F, dzp, nimg, F, sc.gwz, sc.gbz); }
         Epi e4;
         e4.out1 = dA[4]; e4.ld1 = F; e4.mask = act[4]; e4.ldm = F;
         fc_dx(h, scn + "/hz_lin", dzp, nimg, F, sc.wz, F, e4);
-        fc_dw(h, scn + "/h4_lin", nm(act[3], K3, K3, nimg), K3, dA[4], nimg, F, sc.gw4, sc.gb4);
+        { Side sd(h, dw_lane); fc_dw(h, scn + "/h4_lin", nm(act[3], K3, K3, nimg), K3, dA[4], nimg, F, sc.gw4, sc.gb4); }
         Epi e3;
         e3.out1 = dA[3]; e3.ld1 = K3; e3.mask = act[3]; e3.ldm = K3;
         if (with_skips) { e3.add1 = h->dSk[3]; e3.lda1 = K3; e3.add2 = h->dSk[3] + (int64_t)B * K3; e3.lda2 = K3; }
@@ -540,16 +575,19 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             const float* xin = k ? act[k - 1] : x;
             const std::string ln = scn + "/h" + std::to_string(k) + "_conv";
             const double fl = 2.0 * R * 25 * ca * cb;
-            bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
             NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
             Epi eg;
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
             if (k == 0) {
+                Side sd(h, dw_lane);
+                bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
                 conv3_wgrad(h->stream, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 break;   // no gradient w.r.t. the frame
             }
-            { ProfScope ps(h, ln + " dw", K_WGRAD, fl);
+            { Side sd(h, dw_lane);
+              bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
+              ProfScope ps(h, ln + " dw", K_WGRAD, fl);
               if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(nimg, hs, wsm);
                   conv_wgrad_p(h->stream, NmWgradBigP{xin, ca, ca, wb, pg, g_zeros}, NmWgradSmallP{dA[k], cb, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
@@ -572,14 +610,14 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     if (lanes) {
         // `conv_context` (linear hz_lin; its h0..h3 also fed both decoder passes as skips) on the second lane:
         // everything it reads (dcz, dSk[*], c[*]) was produced before this point
-        fork(h);
-        LaneSwap sw(h);
-        encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+        fork(h, LANE_CTX);
+        LaneSwap sw(h, LANE_CTX);
+        encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true, -1);
     }
     { ProfScope ps(h, "conv/hz_lin lrelu'", K_EW, 0.0); lrelu_mask(h->stream, dSz, tgt_z, 2ll * B * F); }
-    encoder_bwd("conv", scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false);
-    if (lanes) join(h);
-    else encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true);
+    encoder_bwd("conv", scope_of(h, "conv"), h->img, 2 * B, h->s, dSz, h->dS, false, LANE_DW);
+    if (lanes) { join(h, LANE_CTX); join(h, LANE_DW); }
+    else encoder_bwd("conv_context", scope_of(h, "conv_context"), h->img + 2 * B * npi, B, h->c, h->dcz, h->dC, true, -1);
     h->have_grads = true;
 
 }
@@ -679,10 +717,11 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     if (rc == CTX_OK) {
         const char* ov = getenv("CTX_OVERLAP");
         h->overlap = !(ov && ov[0] == '0');
-        if (hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess)
-            rc = fail(h, CTX_E_DEVICE, "second-lane stream/event creation failed");
+        for (int l = 0; l < ctx_handle::NLANE && rc == CTX_OK; ++l)
+            if (hipStreamCreateWithFlags(&h->aux[l], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
+                rc = fail(h, CTX_E_DEVICE, "side-lane stream/event creation failed");
     }
     if (rc == CTX_OK) {
         e = hipMemsetAsync(h->arena + h->Ppad, 0, 3 * h->Ppad * sizeof(float), h->stream);   // grads, m, v
@@ -708,9 +747,11 @@ void ctx_destroy(ctx_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
-    if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (int l = 0; l < ctx_handle::NLANE; ++l) {
+        if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
+        if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
+        if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
+    }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
