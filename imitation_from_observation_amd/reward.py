@@ -31,25 +31,41 @@ class TranslatorReward:
         """env_infos['imgs'] holds, every other step, a list over viewpoints of uint8 frames (base.py:193)."""
         return [img for img in path["env_infos"]["imgs"] if img is not None]
 
-    def build_demo_cache(self, validdata, first_frames):
+    def build_demo_cache(self, validdata, first_frames, distributed=False):
         """validdata: demo tensor [T, Nvid, H, W, 3] in [-1,1] (np.load(modeldata), base.py:198);
-        first_frames[vp]: uint8 context frame = first frame of the current rollout (base.py:200)."""
+        first_frames[vp]: uint8 context frame = first frame of the current rollout (base.py:200).
+        distributed=True (inside an initialised torch.distributed group, one rank per GPU): the demo videos
+        are sharded rank::world, every rank translates its shard and the partial feature / frame sums are
+        combined with ONE all-reduce per viewpoint -- the demo means are a plain sum over videos."""
         validdata = np.asarray(validdata)
         nvid = validdata.shape[1]
         bs = self.batch_size
         self.means, self.imgs = [], []
         per_call = max(1, self.tr.max_batch // bs)
+        rank, world = 0, 1
+        if distributed:
+            import torch
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+        mine = list(range(rank, nvid, world))
         for vp in range(self.nvp):
             ctx = np.ascontiguousarray(first_frames[vp], dtype=np.uint8)
             fsum = np.zeros((bs, self.tr.featsize), np.float64)
             isum = np.zeros((bs, self.tr.H, self.tr.W, 3), np.float64)
-            for i0 in range(0, nvid, per_call):
-                vids = range(i0, min(nvid, i0 + per_call))
+            for i0 in range(0, len(mine), per_call):
+                vids = mine[i0:i0 + per_call]
                 # ((validdata[::skip, i] + 1) * 127.5).astype(np.uint8), base.py:215
                 u8 = np.concatenate([((validdata[::self.skip, i][:bs] + 1) * 127.5).astype(np.uint8) for i in vids])
                 timg, tfeat = self.tr.translate(u8, ctx)                   # [translated_z, out], base.py:216-218
                 fsum += tfeat.reshape(len(vids), bs, -1).sum(0)
                 isum += timg.reshape(len(vids), bs, self.tr.H, self.tr.W, 3).sum(0)
+            if distributed and world > 1:
+                flat = torch.from_numpy(np.concatenate([fsum.ravel(), isum.ravel()]))
+                if dist.get_backend() == "nccl":
+                    flat = flat.cuda()
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat = flat.cpu().numpy()
+                fsum, isum = flat[:fsum.size].reshape(fsum.shape), flat[fsum.size:].reshape(isum.shape)
             self.means.append((fsum / nvid).astype(np.float32))            # np.mean(tfeats, axis=0), base.py:221
             self.imgs.append((isum / nvid).astype(np.float32))             # np.mean(timgs, axis=0), base.py:222
         return self

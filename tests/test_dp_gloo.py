@@ -110,3 +110,44 @@ def test_two_rank_data_parallel_equals_full_batch():
     for r in range(world):
         np.testing.assert_allclose(got[r][3], ref.params.numpy(), rtol=1e-9, atol=1e-12)   # two steps later
     np.testing.assert_array_equal(got[0][3], got[1][3])                  # replicas still bit-identical
+
+
+# ------------------------------------------------------------------------------------------------ reward path
+def _reward_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imitation_from_observation_amd.reward import TranslatorReward
+    from tests.test_reward import CFG as RCFG, OracleTranslator, make_world
+    p, validdata, paths = make_world(nvp=2, nvid=7, npaths=2, seed=5)
+    first = [img for img in paths[0]["env_infos"]["imgs"] if img is not None][0]
+    hook = TranslatorReward(OracleTranslator(p, 50), nvp=2, scale=0.01).build_demo_cache(validdata, first, distributed=True)
+    q.put((rank, [m.copy() for m in hook.means], [i.copy() for i in hook.imgs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_demo_cache_sharded_over_ranks_equals_single_process():
+    """SURVEY.md 8e (inference): demo videos sharded over ranks, partial sums combined with one all-reduce."""
+    world = 2
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_reward_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from imitation_from_observation_amd.reward import TranslatorReward
+    from tests.test_reward import OracleTranslator, make_world
+    pr, validdata, paths = make_world(nvp=2, nvid=7, npaths=2, seed=5)
+    first = [img for img in paths[0]["env_infos"]["imgs"] if img is not None][0]
+    ref = TranslatorReward(OracleTranslator(pr, 50), nvp=2, scale=0.01).build_demo_cache(validdata, first)
+    for r in range(world):
+        for vp in range(2):
+            np.testing.assert_allclose(got[r][1][vp], ref.means[vp], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(got[r][2][vp], ref.imgs[vp], rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(got[0][1][0], got[1][1][0])      # every rank ends with the same cache
