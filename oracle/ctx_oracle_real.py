@@ -1,0 +1,186 @@
+"""CPU oracle for ContextAEReal  --  TEST INFRASTRUCTURE ONLY (same rules and same "parity unpinned"
+status as oracle/ctx_oracle.py, whose ops it reuses).
+
+ContextAEReal (gym/envs/mujoco/arm_shaping.py:1599-1684) is the translator the sampler builds for
+name in ('real', 'sweep') (rllab/sampler/base.py:134-135), on 36x64 frames
+(sandbox/andrew/run_trpo_sweep_ours.py:64).  Differences from ContextSkipNew:
+  * ONE encoder (scope "conv") shared by src, tgt and ctx (arm_shaping.py:1642-1647); lrelu on hz_lin for all;
+  * filters nf = 32/16/16/8 with strides ns = 1/2/1/2 (:1622-1629), featsize 100 (:1616);
+  * decoder deconvs mirror the strides: d_h1 s2, d_h2 s1, d_h3 s2, d_h4 s1 (:1664-1671);
+  * tf.nn.dropout(., keep_prob) in front of every linear and on the reshaped d_h0 (:1637-1663) with the
+    module-level keep_prob = 1.0 (:1476) -- the identity, and restated as such.  (ablations_code/ablations.py
+    trains its copy with keep_prob 0.5; that path needs TF's RNG stream and is out of scope.)
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import numpy as np
+
+from .ctx_oracle import KS, conv2d, conv2d_bwd, deconv2d, deconv2d_bwd, linear, lrelu, lrelu_grad
+
+NF = (32, 16, 16, 8)        # nf0..nf3, arm_shaping.py:1622-1625
+NS = (1, 2, 1, 2)           # ns0..ns3, :1626-1629
+
+
+@dataclass(frozen=True)
+class RealConfig:
+    H: int = 36
+    W: int = 64
+    C: int = 3
+    featsize: int = 100     # :1616
+
+    def __post_init__(self):
+        assert self.H % 4 == 0 and self.W % 4 == 0, "two stride-2 layers: H, W divisible by 4"
+
+    @property
+    def sizes(self):
+        """spatial size after each encoder layer: s0..s3 (arm_shaping.py:1654-1657)."""
+        out, h, w = [], self.H, self.W
+        for s in NS:
+            h, w = h // s, w // s
+            out.append((h, w))
+        return out
+
+
+def param_specs(cfg: RealConfig):
+    """TF variable names/shapes (scopes of arm_shaping.py:1642, 1648, 1674; conv2d :24-29, linear :51-55,
+    deconv2d :66-79 with filter [k, k, out, in])."""
+    F = cfg.featsize
+    h3, w3 = cfg.sizes[3]
+    specs, cin = [], cfg.C
+    for k, cout in enumerate(NF):
+        specs += [(f"conv/h{k}_conv/w", (KS, KS, cin, cout)), (f"conv/h{k}_conv/biases", (cout,))]
+        cin = cout
+    specs += [("conv/h4_lin/Matrix", (h3 * w3 * NF[3], F)), ("conv/h4_lin/bias", (F,)),
+              ("conv/hz_lin/Matrix", (F, F)), ("conv/hz_lin/bias", (F,)),
+              ("translate/trans_h0/Matrix", (2 * F, F)), ("translate/trans_h0/bias", (F,)),
+              ("translate/trans_z/Matrix", (F, F)), ("translate/trans_z/bias", (F,)),
+              ("deconv/d_h0_lin/Matrix", (F, NF[3] * h3 * w3)), ("deconv/d_h0_lin/bias", (NF[3] * h3 * w3,)),
+              ("deconv/d_h1/w", (KS, KS, NF[2], 2 * NF[3])), ("deconv/d_h1/biases", (NF[2],)),
+              ("deconv/d_h2/w", (KS, KS, NF[1], 2 * NF[2])), ("deconv/d_h2/biases", (NF[1],)),
+              ("deconv/d_h3/w", (KS, KS, NF[0], 2 * NF[1])), ("deconv/d_h3/biases", (NF[0],)),
+              ("deconv/d_h4/w", (KS, KS, cfg.C, 2 * NF[0])), ("deconv/d_h4/biases", (cfg.C,))]
+    return specs
+
+
+def param_count(cfg):
+    return int(sum(int(np.prod(s)) for _, s in param_specs(cfg)))
+
+
+def init_params(cfg, seed, dtype=np.float64, stddev=0.02):
+    rng = np.random.default_rng(seed)
+    p = OrderedDict()
+    for name, shape in param_specs(cfg):
+        if name.endswith("bias") or name.endswith("biases"):
+            p[name] = np.zeros(shape, dtype)
+        else:
+            p[name] = (rng.standard_normal(shape) * stddev).astype(dtype)
+    return p
+
+
+def flatten(tree, cfg, dtype=None):
+    return np.concatenate([np.asarray(tree[n]).reshape(-1) for n, _ in param_specs(cfg)]).astype(
+        dtype or next(iter(tree.values())).dtype)
+
+
+def _encode(p, img):
+    """arm_shaping.py:1633-1640."""
+    acts, h = [], img
+    for k in range(4):
+        h = lrelu(conv2d(h, p[f"conv/h{k}_conv/w"], p[f"conv/h{k}_conv/biases"], s=NS[k]))
+        acts.append(h)
+    h4 = lrelu(linear(h.reshape(h.shape[0], -1), p["conv/h4_lin/Matrix"], p["conv/h4_lin/bias"]))
+    z = lrelu(linear(h4, p["conv/hz_lin/Matrix"], p["conv/hz_lin/bias"]))
+    return acts + [h4, z]
+
+
+def _decode(p, cfg, z, skips):
+    """arm_shaping.py:1659-1672: d_h0_lin -> [-1, s_h3, s_w3, nf3]; deconvs with strides ns3, ns2, ns1, ns0
+    on concat([decoder, skip_h3 / h2 / h1 / h0], 3)."""
+    h3, w3 = cfg.sizes[3]
+    z_ = lrelu(linear(z, p["deconv/d_h0_lin/Matrix"], p["deconv/d_h0_lin/bias"]))
+    h = z_.reshape(-1, h3, w3, NF[3])
+    hs, cats = [z_], []
+    out_sizes = [cfg.sizes[2], cfg.sizes[1], cfg.sizes[0], (cfg.H, cfg.W)]
+    for k in range(1, 5):
+        cat = np.concatenate([h, skips[4 - k]], axis=3)
+        cats.append(cat)
+        h = deconv2d(cat, p[f"deconv/d_h{k}/w"], p[f"deconv/d_h{k}/biases"], out_sizes[k - 1], s=NS[4 - k])
+        if k < 4:
+            h = lrelu(h)
+        hs.append(h)
+    return hs, cats
+
+
+def forward(p, src, ctx, tgt, cfg: RealConfig):
+    c = {"src": src, "ctx": ctx, "tgt": tgt}
+    c["e_src"], c["e_tgt"], c["e_ctx"] = _encode(p, src), _encode(p, tgt), _encode(p, ctx)     # :1642-1647
+    src_z, ctx_z, tgt_z = c["e_src"][5], c["e_ctx"][5], c["e_tgt"][5]
+    c["tcat"] = np.concatenate([src_z, ctx_z], axis=1)
+    c["trans_h0"] = lrelu(linear(c["tcat"], p["translate/trans_h0/Matrix"], p["translate/trans_h0/bias"]))
+    c["trans_z"] = linear(c["trans_h0"], p["translate/trans_z/Matrix"], p["translate/trans_z/bias"])
+    skips = c["e_ctx"][:4]
+    c["d1"], c["d1_cats"] = _decode(p, cfg, c["trans_z"], skips)
+    c["d2"], c["d2_cats"] = _decode(p, cfg, tgt_z, skips)
+    out, out2 = c["d1"][4], c["d2"][4]
+    res = {"input_z": src_z, "translated_z": c["trans_z"], "out": out, "out2": out2,
+           "simloss": np.mean((c["trans_z"] - tgt_z) ** 2) * 1e3,          # :1676
+           "recon1": 0.5 * np.sum((tgt - out) ** 2), "recon2": 0.5 * np.sum((tgt - out2) ** 2)}
+    res["loss"] = res["recon1"] + res["recon2"] + res["simloss"]
+    return res, c
+
+
+def backward(p, c, cfg: RealConfig, sim_batch=None):
+    g = OrderedDict((n, None) for n, _ in param_specs(cfg))
+    tgt = c["tgt"]
+    B, F = tgt.shape[0], cfg.featsize
+    tgt_z = c["e_tgt"][5]
+    dsim = (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)
+
+    def acc(name, val):
+        g[name] = val if g[name] is None else g[name] + val
+
+    def lin_bwd(name, x, dy):
+        acc(f"{name}/Matrix", x.T @ dy)
+        acc(f"{name}/bias", dy.sum(0))
+        return dy @ p[f"{name}/Matrix"].T
+
+    def decode_bwd(hs, cats, dout):
+        dskips, dh = [None] * 4, dout
+        for k in range(4, 0, -1):
+            if k < 4:
+                dh = lrelu_grad(hs[k], dh)
+            dcat, dw, db = deconv2d_bwd(cats[k - 1], p[f"deconv/d_h{k}/w"], dh, s=NS[4 - k])
+            acc(f"deconv/d_h{k}/w", dw)
+            acc(f"deconv/d_h{k}/biases", db)
+            Cd = cats[k - 1].shape[3] // 2
+            dskips[4 - k], dh = dcat[..., Cd:], dcat[..., :Cd]
+        return lrelu_grad(hs[0], dh.reshape(B, -1)), dskips
+
+    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] - tgt)
+    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] - tgt)
+    dtrans_z = lin_bwd("deconv/d_h0_lin", c["trans_z"], dz1_) + dsim
+    dtgt_z = lin_bwd("deconv/d_h0_lin", tgt_z, dz2_) - dsim
+    dth0 = lrelu_grad(c["trans_h0"], lin_bwd("translate/trans_z", c["trans_h0"], dtrans_z))
+    dtcat = lin_bwd("translate/trans_h0", c["tcat"], dth0)
+
+    def encode_bwd(img, acts, dz, dskips=None):
+        dz = lrelu_grad(acts[5], dz)
+        dh4 = lrelu_grad(acts[4], lin_bwd("conv/hz_lin", acts[4], dz))
+        dh = lin_bwd("conv/h4_lin", acts[3].reshape(B, -1), dh4).reshape(acts[3].shape)
+        for k in range(3, -1, -1):
+            if dskips is not None:
+                dh = dh + dskips[k]
+            dh = lrelu_grad(acts[k], dh)
+            x = acts[k - 1] if k > 0 else img
+            dx, dw, db = conv2d_bwd(x, p[f"conv/h{k}_conv/w"], dh, s=NS[k], need_dx=(k > 0))
+            acc(f"conv/h{k}_conv/w", dw)
+            acc(f"conv/h{k}_conv/biases", db)
+            dh = dx
+
+    encode_bwd(c["src"], c["e_src"], dtcat[:, :F])
+    encode_bwd(c["tgt"], c["e_tgt"], dtgt_z)
+    encode_bwd(c["ctx"], c["e_ctx"], dtcat[:, F:], dskips=[a + b for a, b in zip(dsk1, dsk2)])
+    return g

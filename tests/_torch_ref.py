@@ -57,3 +57,52 @@ def forward(p, src, ctx, tgt, H, W, gf):
     r2 = 0.5 * ((tgt - out2) ** 2).sum()
     return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1,
                 recon2=r2, loss=r1 + r2 + sim)
+
+
+# ------------------------------------------------------------------------------------------------ ContextAEReal
+def tf_conv_s(x_nhwc, w_hwio, b, s):
+    """SAME conv for stride 1 (pad 2/2) or 2 on an even input (pad 1/2)."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x = F.pad(x, (2, 2, 2, 2)) if s == 1 else F.pad(x, (1, 2, 1, 2))
+    return F.conv2d(x, w_hwio.permute(3, 2, 0, 1), b, stride=s).permute(0, 2, 3, 1)
+
+
+def tf_deconv_s(x_nhwc, w_hwoi, b, s):
+    x = x_nhwc.permute(0, 3, 1, 2)
+    h, w = x.shape[2:]
+    full = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=s, padding=0)
+    pb = 2 if s == 1 else 1                              # SAME pad_before of the conv this is the gradient of
+    y = full[:, :, pb:pb + s * h, pb:pb + s * w] + b.view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1)
+
+
+def forward_real(p, src, ctx, tgt, H, W):
+    """ContextAEReal (arm_shaping.py:1599-1684), keep_prob = 1."""
+    NS = (1, 2, 1, 2)
+
+    def enc(img):
+        acts, h = [], img
+        for k in range(4):
+            h = lrelu(tf_conv_s(h, p[f"conv/h{k}_conv/w"], p[f"conv/h{k}_conv/biases"], NS[k]))
+            acts.append(h)
+        h4 = lrelu(h.reshape(h.shape[0], -1) @ p["conv/h4_lin/Matrix"] + p["conv/h4_lin/bias"])
+        return acts, lrelu(h4 @ p["conv/hz_lin/Matrix"] + p["conv/hz_lin/bias"])
+
+    def dec(z, skips):
+        h = lrelu(z @ p["deconv/d_h0_lin/Matrix"] + p["deconv/d_h0_lin/bias"]).reshape(-1, H // 4, W // 4, 8)
+        for k in range(1, 5):
+            h = tf_deconv_s(torch.cat([h, skips[4 - k]], 3), p[f"deconv/d_h{k}/w"], p[f"deconv/d_h{k}/biases"], NS[4 - k])
+            if k < 4:
+                h = lrelu(h)
+        return h
+
+    _, src_z = enc(src)
+    _, tgt_z = enc(tgt)
+    skips, ctx_z = enc(ctx)
+    th0 = lrelu(torch.cat([src_z, ctx_z], 1) @ p["translate/trans_h0/Matrix"] + p["translate/trans_h0/bias"])
+    trans_z = th0 @ p["translate/trans_z/Matrix"] + p["translate/trans_z/bias"]
+    out, out2 = dec(trans_z, skips), dec(tgt_z, skips)
+    sim = ((trans_z - tgt_z) ** 2).mean() * 1e3
+    r1 = 0.5 * ((tgt - out) ** 2).sum()
+    r2 = 0.5 * ((tgt - out2) ** 2).sum()
+    return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1, recon2=r2, loss=r1 + r2 + sim)
