@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libctxtrans.so")
 
 CTX_OK, CTX_E_INVALID, CTX_E_DEVICE, CTX_E_NOMEM, CTX_E_STATE = 0, -1, -2, -3, -4
 CTX_VARIANT_SKIPNEW = 0
+CTX_VARIANT_REAL = 1
 
 
 class CtxConfig(ctypes.Structure):

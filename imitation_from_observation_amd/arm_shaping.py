@@ -42,6 +42,8 @@ class ContextSkipNew:
         for f in _FETCHES:                                 # fetch handles: model.out etc.
             setattr(self, f, f)
 
+    variant = "skipnew"
+
     def build(self, image, device=0, seed=None):
         """`image`: the placeholder's shape (3, batch, H, W, 3) or an array of that shape."""
         shape = tuple(getattr(image, "shape", image))
@@ -49,7 +51,7 @@ class ContextSkipNew:
             raise ValueError(f"expected (3, batch, H, W, {self.c_dim}), got {shape}")
         self.batch_size, self.output_height, self.output_width = shape[1], shape[2], shape[3]
         self.translator = Translator(self.output_height, self.output_width, self.df_dim, self.featsize,
-                                     max_batch=self.batch_size, device=device)
+                                     max_batch=self.batch_size, device=device, variant=self.variant)
         if seed is not None:
             self.translator.init_params(seed)              # tf.global_variables_initializer
         return self
@@ -99,3 +101,14 @@ class ContextSkipNew:
                 res["translated_z"], res["input_z"] = z[0], z[2]
         out = [res[n] for n in names]
         return out[0] if single else out
+
+
+class ContextAEReal(ContextSkipNew):
+    """gym/envs/mujoco/arm_shaping.py:1599-1684 -- the model the sampler builds for name in ('real', 'sweep')
+    (rllab/sampler/base.py:134-135): one shared encoder, filters 32/16/16/8 with strides 1/2/1/2, featsize 100
+    (hard-coded in build(), :1616), keep_prob = 1 (:1476).  Same constructor and fetch names."""
+    variant = "real"
+
+    def __init__(self, gf_dim=64, df_dim=64, gfc_dim=1024, dfc_dim=1024, c_dim=3):
+        super().__init__(gf_dim, df_dim, gfc_dim, dfc_dim, c_dim)
+        self.featsize = 100

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <random>
 #include <string>
 #include <vector>
@@ -45,8 +46,12 @@ struct ParamInfo {
 
 }  // namespace
 
+namespace { struct RealState; }
+
 struct ctx_handle {
     ctx_config cfg{};
+    RealState* real = nullptr;   // CTX_VARIANT_REAL state (ctxtrans_real.inc)
+    int Fp = 0;                  // row stride of the code buffers Z / dZ (featsize, or featsize padded to 32 for REAL)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -157,8 +162,15 @@ struct ProfScope {
 
 int check_cfg(const ctx_config* c, ctx_handle* h) {
     if (!c) return fail(h, CTX_E_INVALID, "cfg is NULL");
-    if (c->variant != CTX_VARIANT_SKIPNEW) return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
+    if (c->variant != CTX_VARIANT_SKIPNEW && c->variant != CTX_VARIANT_REAL)
+        return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
     if (c->C != 3) return fail(h, CTX_E_INVALID, "C must be 3");
+    if (c->variant == CTX_VARIANT_REAL) {   // ContextAEReal: two stride-2 layers, fixed filters 32/16/16/8
+        if (c->H <= 0 || c->W <= 0 || c->H % 4 || c->W % 4) return fail(h, CTX_E_INVALID, "H, W must be positive multiples of 4 (got %dx%d)", c->H, c->W);
+        if (c->featsize <= 0 || c->featsize % 4) return fail(h, CTX_E_INVALID, "featsize must be a multiple of 4");
+        if (c->max_batch <= 0) return fail(h, CTX_E_INVALID, "max_batch must be positive");
+        return CTX_OK;
+    }
     if (c->H <= 0 || c->W <= 0 || c->H % 16 || c->W % 16)
         return fail(h, CTX_E_INVALID, "H, W must be positive multiples of 16 (got %dx%d)", c->H, c->W);
     if (c->df_dim <= 0 || c->df_dim % 32) return fail(h, CTX_E_INVALID, "df_dim must be a multiple of 32");
@@ -426,10 +438,15 @@ void encoder_fwd(ctx_handle* h, const std::string& scn, const Scope& sc, const f
 
 enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
 
+}  // namespace
+#include "ctxtrans_real.inc"
+namespace {
+
 // Forward.  TRAIN/EVAL: st = [tgt | src] (2B), decoder = [translated | truth] (2B).
 // TRANSLATE: only what translated_z / out depend on (src encoder, ctx encoder, translate, decoder
 // pass 1) -- the subgraph TF would run for base.py:216-218.  ENCODE: `conv` encoder on src only.
 void forward(ctx_handle* h, int B, Mode mode) {
+    if (h->real) { real_forward(h, B, mode); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
@@ -484,6 +501,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
 // d loss / d params into the grad arena (what AdamOptimizer.minimize differentiates,
 // scripts/train_script.py:128).  Every gradient tensor is written exactly once.
 void backward(ctx_handle* h, int B, int sim_batch) {
+    if (h->real) { real_backward(h, B, sim_batch); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
@@ -667,11 +685,23 @@ int64_t ctx_param_total_for(const ctx_config* cfg) {
     if (check_cfg(cfg, nullptr) != CTX_OK) return CTX_E_INVALID;
     std::vector<ParamInfo> ps;
     int64_t total = 0;
-    build_params(*cfg, ps, total);
+    if (cfg->variant == CTX_VARIANT_REAL) {
+        RealState r;
+        int64_t pp = 0;
+        real_layout(*cfg, r, ps, total, pp);
+    } else build_params(*cfg, ps, total);
     return total;
 }
 
 int64_t ctx_arena_bytes(const ctx_config* cfg) {
+    if (check_cfg(cfg, nullptr) != CTX_OK) return CTX_E_INVALID;
+    if (cfg->variant == CTX_VARIANT_REAL) {   // the arena holds the zero-padded parameters
+        RealState r;
+        std::vector<ParamInfo> ps;
+        int64_t total = 0, pp = 0;
+        real_layout(*cfg, r, ps, total, pp);
+        return 4 * pp * (int64_t)sizeof(float);
+    }
     const int64_t p = ctx_param_total_for(cfg);
     return p < 0 ? p : 4 * round_up(p, 64) * (int64_t)sizeof(float);
 }
@@ -695,10 +725,17 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     for (int k = 0; k < 5; ++k) { h->hh[k] = cfg->H >> k; h->ww[k] = cfg->W >> k; }
     h->npi = (int64_t)cfg->H * cfg->W * 3;
     h->D0 = (int64_t)8 * h->d * h->hh[4] * h->ww[4];
-    build_params(*cfg, h->params, h->P);
-    h->Ppad = round_up(h->P, 64);
-    for (auto& p : h->params)
-        if (p.offset % 4) { delete h; return fail(nullptr, CTX_E_INVALID, "parameter %s not 16-byte aligned in the arena", p.name.c_str()); }
+    h->Fp = h->F;
+    if (cfg->variant == CTX_VARIANT_REAL) {
+        h->real = new RealState();
+        real_layout(*cfg, *h->real, h->params, h->P, h->Ppad);
+        h->Fp = h->real->Fp;
+    } else {
+        build_params(*cfg, h->params, h->P);
+        h->Ppad = round_up(h->P, 64);
+        for (auto& p : h->params)
+            if (p.offset % 4) { delete h; return fail(nullptr, CTX_E_INVALID, "parameter %s not 16-byte aligned in the arena", p.name.c_str()); }
+    }
     int rc = CTX_OK;
     if (stream) h->stream = (hipStream_t)stream;
     else {
@@ -713,7 +750,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
             h->own_arena = true;
         }
     }
-    if (rc == CTX_OK) rc = alloc_buffers(h);
+    if (rc == CTX_OK) rc = h->real ? real_alloc(h) : alloc_buffers(h);
     if (rc == CTX_OK) {
         const char* ov = getenv("CTX_OVERLAP");
         h->overlap = !(ov && ov[0] == '0');
@@ -747,6 +784,7 @@ void ctx_destroy(ctx_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
+    delete h->real;
     for (int l = 0; l < ctx_handle::NLANE; ++l) {
         if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
         if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
@@ -776,6 +814,19 @@ static int arena_io(ctx_handle* h, int slot, float* host, const float* chost, si
     if ((int64_t)n != h->P) return fail(h, CTX_E_INVALID, "expected %lld floats, got %zu", (long long)h->P, n);
     HIP_TRY(h, hipSetDevice(h->device));
     float* dev = h->arena + slot * h->Ppad;
+    if (h->real) {   // scatter / gather between the TF-shaped vector and the zero-padded arena
+        std::vector<float> padded((size_t)h->Ppad, 0.f);
+        const std::vector<int32_t>& map = h->real->real2pad;
+        if (chost) {
+            for (size_t i = 0; i < n; ++i) padded[(size_t)map[i]] = chost[i];
+            HIP_TRY(h, hipMemcpyAsync(dev, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            return finish(h);
+        }
+        HIP_TRY(h, hipMemcpyAsync(padded.data(), dev, padded.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        TRY(finish(h));
+        for (size_t i = 0; i < n; ++i) host[i] = padded[(size_t)map[i]];
+        return CTX_OK;
+    }
     if (chost) HIP_TRY(h, hipMemcpyAsync(dev, chost, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
     else HIP_TRY(h, hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return finish(h);
@@ -834,9 +885,14 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
     u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
     if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, B * npi);
     else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi, B);
+    if (h->real) {   // the shared encoder also runs on the tgt slot: image[2] = [context]*B there (base.py:217-218)
+        if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img, B * npi);
+        else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img, npi, B);
+    }
     forward(h, B, MODE_TRANSLATE);
     if (pred) HIP_TRY(h, hipMemcpyAsync(pred, h->out, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (feat) HIP_TRY(h, hipMemcpyAsync(feat, h->Z, (size_t)B * h->F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z, h->Fp * sizeof(float), h->F * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, h->stream));
     h->last_B = 0;
     return finish(h);
 }
@@ -849,7 +905,8 @@ int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* 
     HIP_TRY(h, hipMemcpyAsync(h->u8, frames, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, h->u8, h->img + B * npi, B * npi);
     forward(h, B, MODE_ENCODE);
-    if (feat) HIP_TRY(h, hipMemcpyAsync(feat, h->Z + 2ll * B * h->F, (size_t)B * h->F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, h->stream));
     if (frames_f32) HIP_TRY(h, hipMemcpyAsync(frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->last_B = 0;
     return finish(h);
@@ -864,7 +921,7 @@ int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const
     HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
     forward(h, B, MODE_TRAIN);
-    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->F, nullptr, h->F, B, h->scratch, h->scalars);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
     return CTX_OK;
@@ -918,7 +975,7 @@ int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const 
     const int B = h->last_B;
     if (out) *out = h->out;
     if (out2) *out2 = h->out + B * h->npi;
-    if (input_z) *input_z = h->Z + 2ll * B * h->F;
+    if (input_z) *input_z = h->Z + 2ll * B * h->Fp;   // row stride Fp (== featsize except for the padded REAL variant)
     if (translated_z) *translated_z = h->Z;
     return CTX_OK;
 }
@@ -959,7 +1016,7 @@ int ctx_eval(ctx_handle* h, const float* src, const float* ctxf, const float* tg
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_f32(h, src, ctxf, tgt, B));
     forward(h, B, MODE_TRAIN);
-    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->F, nullptr, h->F, B, h->scratch, h->scalars);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
     h->last_B = B;
     const size_t bytes = (size_t)B * h->npi * sizeof(float);
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

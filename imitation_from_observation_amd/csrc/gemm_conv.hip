@@ -19,6 +19,9 @@ void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, floa
     ep.out1 = P; ep.ld1 = P3_LD;
     launch_igemm(s, a, b, ep, M, 75, 1, 0, ws);
 }
+void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
+    launch_igemm(s, a, b, ep, M, N, 1, 25 * a.cps, ws);
+}
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, 3, ws);
 }

@@ -191,40 +191,53 @@ struct KmPlain {
     __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v1 : c.v0); }
 };
 
-// conv2d forward operand: row m = (img, i, j) of the OUTPUT grid; segment = tap (ky,kx); the run is
-// the cin channels of input pixel (2i+ky-1, 2j+kx-1)  [TF SAME for k=5, s=2, even input: pad 1 / 2].
+// conv2d forward operand: row m = (img, i, j) of the OUTPUT grid; segment = tap (ky,kx); the run is the cin
+// channels of input pixel (s*i + ky - pad, s*j + kx - pad): TF SAME for k = 5 is pad 1 (s = 2, even input;
+// 2 after) or pad 2 (s = 1).  flip = 1 reads pixel (i + pad - ky, j + pad - kx) instead: the stride-1
+// conv2d_transpose written as a correlation (ContextAEReal's d_h2 / d_h4 and the input gradient of its
+// stride-1 convs).  Channels may come from two tensors [x | x2] (x2 = ctx skip, image index img % nmod2).
 // K order: 32-channel slice outer, the 25 taps inner.
 struct KmConvGather {
     static constexpr bool KM = true;
     const float* x; int64_t ldx;   // NHWC input, channel stride ldx
     int hb, wb, hs, ws;            // input (big) and output (small) grids
-    int cps;                       // chunks per tap = cin / 32
+    int cps;                       // chunks per tap = (c1 + c2) / 32
     int R;                         // imgs * hs * ws
     const float* zeros;
     int tap_outer = 0;             // K order: 0 = channel slice outer / taps inner, 1 = taps outer
-    struct Pos { rsrc_t rs; int seg; };
-    struct Ctx { uint32_t v; unsigned mask; };   // v -> input pixel (2i, 2j); mask bit = tap valid
+    int s = 2, pad = 1, flip = 0;
+    const float* x2 = nullptr; int64_t ldx2 = 0; int c1 = 1 << 30; int nmod2 = 1;
+    struct Pos { rsrc_t rs; int seg; bool second; };
+    struct Ctx { uint32_t v, v2; unsigned mask; };   // v -> input pixel (s*i, s*j); mask bit = tap valid
     __device__ int nchunks_of(int) const { return 25 * cps; }
     __device__ Pos pos(int, int chunk) const {
         int seg, slice;
         if (tap_outer) { seg = chunk / cps; slice = chunk - seg * cps; }
         else tap_slice(chunk, 25, seg, slice);
         const int ky = seg / 5, kx = seg - ky * 5;
-        return Pos{make_rsrc(x + ((int64_t)(ky - 1) * wb + (kx - 1)) * ldx + slice * KC), seg};
+        const int64_t off = (int64_t)(flip ? pad - ky : ky - pad) * wb + (flip ? pad - kx : kx - pad);
+        const int kc = slice * KC;
+        const bool second = kc >= c1;
+        return Pos{make_rsrc(second ? x2 + off * ldx2 + (kc - c1) : x + off * ldx + kc), seg, second};
     }
     __device__ void prep(int, int row, int k4, Ctx& c) const {
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        const int i2 = 2 * i - 1, j2 = 2 * j - 1;
-        c.v = (uint32_t)((((int64_t)n * hb + 2 * i) * wb + 2 * j) * ldx + k4) * 4u;
+        const int64_t pix = (int64_t)(s * i) * wb + s * j;
+        c.v = (uint32_t)(((int64_t)n * hb * wb + pix) * ldx + k4) * 4u;
+        c.v2 = (uint32_t)(((int64_t)(n % nmod2) * hb * wb + pix) * ldx2 + k4) * 4u;
         unsigned m = 0;
 #pragma unroll
         for (int ky = 0; ky < 5; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 5; ++kx)
-                if ((unsigned)(i2 + ky) < (unsigned)hb && (unsigned)(j2 + kx) < (unsigned)wb) m |= 1u << (ky * 5 + kx);
+            for (int kx = 0; kx < 5; ++kx) {
+                const int y = s * i + (flip ? pad - ky : ky - pad), xx = s * j + (flip ? pad - kx : kx - pad);
+                if ((unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb) m |= 1u << (ky * 5 + kx);
+            }
         c.mask = row < R ? m : 0u;
     }
-    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, (c.mask >> q.seg) & 1u ? c.v : OOB); }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        return bload4(q.rs, (c.mask >> q.seg) & 1u ? (q.second ? c.v2 : c.v) : OOB);
+    }
 };
 
 // conv2d_transpose operand for output parity class prob = (py,px): row m = (img, i', j') with output
@@ -277,10 +290,16 @@ struct KmConvTWeights {
     const float* w; int ca, cb;    // cb = c1 + c2
     int cps;
     const float* zeros;
+    int flip25 = 0;                // 1: B operand of KmConvGather{flip = 1}: all 25 taps, tap index = seg itself
     struct Pos { rsrc_t rs; };
     struct Ctx { uint32_t v; };
     __device__ int nchunks_of(int) const { return 0; }
     __device__ Pos pos(int prob, int chunk) const {
+        if (flip25) {              // out[y,x,c] = sum in[y+pad-ky, x+pad-kx, k] * w[ky,kx,c,k]: same (ky,kx) on both sides
+            int seg, slice;
+            tap_slice(chunk, 25, seg, slice);
+            return Pos{make_rsrc(w + (int64_t)seg * ca * cb + slice * KC)};
+        }
         const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
         int seg, slice;
         tap_slice(chunk, ntap, seg, slice);
@@ -329,14 +348,15 @@ struct KmC3Gather {
     int hb, wb, hs, ws;
     int R;
     const float* zeros;
+    int s = 2, pad = 1;            // (1, 2) for the stride-1 layers of ContextAEReal
     struct Pos { int chunk; };
-    struct Ctx { const float* base; int i2, j2, k4; bool ok; };   // base -> element (2i-1, 2j-1, 0)
+    struct Ctx { const float* base; int i2, j2, k4; bool ok; };   // base -> element (s*i-pad, s*j-pad, 0)
     __device__ int nchunks_of(int) const { return 3; }
     __device__ Pos pos(int, int chunk) const { return Pos{chunk}; }
     __device__ void prep(int, int row, int k4, Ctx& c) const {
         c.ok = row < R; c.k4 = k4;
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        c.i2 = 2 * i - 1; c.j2 = 2 * j - 1;
+        c.i2 = s * i - pad; c.j2 = s * j - pad;
         c.base = x + (((int64_t)n * hb + c.i2) * wb + c.j2) * 3;
     }
     __device__ float4 load(const Ctx& c, const Pos& q) const {
@@ -438,6 +458,7 @@ struct NmWgradBig {
     PixDiv pd;
     int npix;        // imgs * hs * ws
     const float* zeros;
+    int s = 2, pad = 1;
     struct Pos { rsrc_t rs; int k0, ky, kx; };
     struct Ctx { int kk; uint32_t r; };           // r = channel byte offset or OOB
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
@@ -450,7 +471,7 @@ struct NmWgradBig {
         const int p = q.k0 + c.kk;
         int n, i, j;
         pd.split(p, n, i, j);
-        const int y = 2 * i + q.ky - 1, xx = 2 * j + q.kx - 1;
+        const int y = s * i + q.ky - pad, xx = s * j + q.kx - pad;
         const bool ok = p < npix && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb;
         const uint32_t v = (uint32_t)(((n * hb + y) * wb + xx) * (int)ldb) * 4u + c.r;   // c.r == OOB keeps it out of range
         return bload4(q.rs, ok ? v : OOB);
@@ -617,6 +638,7 @@ struct NmC3WgradBig {
     PixDiv pd;
     int npix;
     const float* zeros;
+    int s = 2, pad = 1;
     struct Pos { int k0; };
     struct Ctx { int kk, r4; };
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
@@ -627,7 +649,7 @@ struct NmC3WgradBig {
         const int ky = c.r4 >> 4;
         int n, i, j;
         pd.split(p, n, i, j);
-        const int y = 2 * i + ky - 1, j2 = 2 * j - 1;
+        const int y = s * i + ky - pad, j2 = s * j - pad;
         const bool rowok = p < npix && ky < 5 && (unsigned)y < (unsigned)hb;
         const float* rowp = big + ((((int64_t)n * hb + y) * wb) + j2) * 3;
         float v[4];

@@ -59,6 +59,37 @@ __global__ __launch_bounds__(NTHREADS) void convt3_gather_kernel(const float* __
     }
 }
 
+__global__ __launch_bounds__(NTHREADS) void convt3_gather_s1_kernel(const float* __restrict__ P, const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int nimg, int hs, int ws) {
+    const int64_t total = (int64_t)nimg * hs * ws;
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
+        const int x = (int)(idx % ws);
+        const int64_t t = idx / ws;
+        const int y = (int)(t % hs), n = (int)(t / hs);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int ky = 0; ky < 5; ++ky) {
+            const int i = y + 2 - ky;
+            if ((unsigned)i >= (unsigned)hs) continue;
+            for (int kx = 0; kx < 5; ++kx) {
+                const int j = x + 2 - kx;
+                if ((unsigned)j >= (unsigned)ws) continue;
+                const float* r = P + (((int64_t)n * hs + i) * ws + j) * P3_LD + (ky * 5 + kx) * 3;
+                a0 += r[0]; a1 += r[1]; a2 += r[2];
+            }
+        }
+        float* o = out + idx * 3;
+        o[0] = a0 + b0; o[1] = a1 + b1; o[2] = a2 + b2;
+    }
+}
+
+void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {
+    const int64_t total = (int64_t)nimg * hs * ws;
+    int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(convt3_gather_s1_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, P, bias, out, nimg, hs, ws);
+}
+
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {
     const int64_t total = (int64_t)nimg * 4 * hs * ws;
     int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
@@ -203,16 +234,18 @@ __global__ void loss_final_kernel(const float* __restrict__ partial, int nblk, d
 }
 
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
-            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars) {
+            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real) {
+    // F = row stride of the code buffers (zero-padded beyond F_real); the simloss mean runs over B x F_real
+    if (F_real <= 0) F_real = F;
     const int64_t half = npi * B, nz = (int64_t)B * F;
     int64_t blocks = (half / 4 + NTHREADS - 1) / NTHREADS;
     if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
     if (blocks < 1) blocks = 1;
-    const float csim = (float)(2e3 / ((double)sim_batch * F));
+    const float csim = (float)(2e3 / ((double)sim_batch * F_real));
     hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, out, tgt, dout, half, tz, tgt_z,
                        dsim2, nz, csim, scratch);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, (int)blocks, 1.0 / (double)nz,
-                       scalars);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, (int)blocks,
+                       1.0 / ((double)B * F_real), scalars);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -28,6 +28,8 @@ void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi
 // power-of-two grids: patch-ordered K (see igemm.h PatchGeo)
 void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws);
+// stride-1 conv2d_transpose as a flipped stride-1 correlation (a.flip = 1, b.flip25 = 1); filter rows as B
+void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws);
@@ -38,6 +40,8 @@ void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, 
 constexpr int P3_LD = 80;                   // row stride of P (75 used)
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
+// stride-1 variant: out[n,y,x,c] = b[c] + sum_{ky,kx} P[(n, y+2-ky, x+2-kx)][(ky*5+kx)*3+c]
+void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
 
 // (x * 1/255 - 0.5) * 2 in unfused f32 ops (rllab/sampler/base.py:116-119)
 void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
@@ -55,7 +59,7 @@ void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t n
 //   scalars[4] = {loss, simloss, recon1, recon2};  scratch: >= 4 * LOSS_BLOCKS floats
 constexpr int LOSS_BLOCKS = 512;
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
-            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars);
+            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real = 0);
 
 // db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * max(C, 4) floats
 constexpr int COLSUM_SPLITS = 256;

@@ -51,9 +51,15 @@ class Translator:
     Thread-compatible, not thread-safe -- like the single tf.Session it replaces.
     """
 
-    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None):
+    VARIANTS = {"skipnew": _lib.CTX_VARIANT_SKIPNEW, "real": _lib.CTX_VARIANT_REAL}
+
+    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None,
+                 variant="skipnew"):
+        """variant "skipnew": ContextSkipNew (sampler names push/reach/strike/throw); "real": ContextAEReal
+        (names real/sweep; pass H=36, W=64, featsize=100 -- df_dim is ignored, rllab/sampler/base.py:134-137)."""
         self._lib = _lib.load()
-        self.cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, max_batch, 0)
+        self.variant = variant
+        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, 3, df_dim, featsize, max_batch, 0)
         self.H, self.W, self.df_dim, self.featsize, self.max_batch = H, W, df_dim, featsize, max_batch
         self.device = device
         self._h = ctypes.c_void_p()
@@ -87,13 +93,13 @@ class Translator:
         _lib.check(self._lib, self._h, rc)
 
     @staticmethod
-    def param_total(H=64, W=64, df_dim=64, featsize=1024):
-        cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, 1, 0)
+    def param_total(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew"):
+        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, 3, df_dim, featsize, 1, 0)
         return int(_lib.load().ctx_param_total_for(ctypes.byref(cfg)))
 
     @staticmethod
-    def arena_floats(H=64, W=64, df_dim=64, featsize=1024):
-        cfg = CtxConfig(_lib.CTX_VARIANT_SKIPNEW, H, W, 3, df_dim, featsize, 1, 0)
+    def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew"):
+        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, 3, df_dim, featsize, 1, 0)
         return int(_lib.load().ctx_arena_bytes(ctypes.byref(cfg))) // 4
 
     # ------------------------------------------------------------------ parameters (tf.train.Saver)

@@ -50,7 +50,10 @@ enum {
 };
 
 enum {
-    CTX_VARIANT_SKIPNEW = 0 /* ContextSkipNew, gym/envs/mujoco/arm_shaping.py:1260-1354 */
+    CTX_VARIANT_SKIPNEW = 0, /* ContextSkipNew, gym/envs/mujoco/arm_shaping.py:1260-1354 */
+    CTX_VARIANT_REAL = 1     /* ContextAEReal, arm_shaping.py:1599-1684 (sampler names 'real', 'sweep'): shared
+                                encoder, filters 32/16/16/8, strides 1/2/1/2; H, W multiples of 4, featsize (100)
+                                a multiple of 4, df_dim ignored, keep_prob = 1 */
 };
 
 typedef struct ctx_config {

@@ -1,0 +1,106 @@
+"""ContextAEReal (CTX_VARIANT_REAL) through the C ABI against oracle/ctx_oracle_real.py: the padded-channel execution
+must reproduce the TF-shaped model exactly (outputs, every gradient, Adam), at the reference's 36x64 size."""
+import numpy as np
+import pytest
+
+from oracle import ctx_oracle as o
+from oracle import ctx_oracle_real as r
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import Translator
+    return Translator
+
+
+def make(H, W, B, seed=0, stddev=0.1):
+    cfg = r.RealConfig(H=H, W=W)
+    p = r.init_params(cfg, 40 + seed, np.float64, stddev=stddev)
+    brng = np.random.default_rng(seed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    rng = np.random.default_rng(seed)
+    fr = [rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8) for _ in range(3)]
+    return cfg, p, fr
+
+
+def test_param_inventory(T):
+    cfg = r.RealConfig()
+    with T(36, 64, featsize=100, max_batch=1, variant="real") as tr:
+        info = tr.param_info()
+        assert tr.n_params == r.param_count(cfg)
+    assert [(n, s) for n, s, _ in info] == [(n, tuple(s)) for n, s in r.param_specs(cfg)]
+
+
+@pytest.mark.parametrize("H,W,B", [(36, 64, 3), (12, 8, 2), (16, 16, 5)])
+def test_real_forward_backward_matches_oracle(T, H, W, B):
+    cfg, p, fr = make(H, W, B)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    res, c = r.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = r.backward(p, c, cfg)
+    with T(H, W, featsize=100, max_batch=B, variant="real") as tr:
+        tr.set_params(p)
+        np.testing.assert_array_equal(tr.get_params_flat(), r.flatten(p, cfg, np.float32))   # pack/unpack round trip
+        ev = tr.evaluate(src, ctx, tgt)
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(ev[k] - res[k]) <= 1e-5 * abs(res[k]) + 1e-6, k
+        assert relmax(ev["out"], res["out"]) < 1e-5 and relmax(ev["out2"], res["out2"]) < 1e-5
+        sc = tr.train_step(src, ctx, tgt, lr=0.0)
+        assert abs(sc["loss"] - res["loss"]) <= 1e-5 * abs(res["loss"])
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-4, n
+        # inference call sites (base.py:216-218, 234-235)
+        pred, feat = tr.translate(fr[0], fr[1][0])
+        c0 = np.broadcast_to(o.preprocess_u8(fr[1][0]), src.shape).astype(np.float64)
+        tres, _ = r.forward(p, src.astype(np.float64), c0, c0, cfg)
+        assert relmax(pred, tres["out"]) < 1e-5 and relmax(feat, tres["translated_z"]) < 1e-5
+        f, x = tr.encode(fr[2])
+        np.testing.assert_array_equal(x, tgt)
+        assert relmax(f, r._encode(p, tgt.astype(np.float64))[5]) < 1e-5
+
+
+def test_real_adam_step_and_determinism(T):
+    H, W, B = 36, 64, 4
+    cfg, p, fr = make(H, W, B, seed=3)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    q = {k: v.copy() for k, v in p.items()}
+    m = {k: np.zeros_like(v) for k, v in q.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in q.items()}
+    with T(H, W, featsize=100, max_batch=B, variant="real") as a, T(H, W, featsize=100, max_batch=B, variant="real") as b:
+        a.set_params(p)
+        b.set_params(p)
+        for t in range(1, 3):
+            res, c = r.forward(q, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+            g = r.backward(q, c, cfg)
+            o.adam_step(q, g, m, v, t, 1e-3)
+            sa = a.train_step(src, ctx, tgt, lr=1e-3)
+            sb = b.train_step_u8(fr[0], fr[1], fr[2], lr=1e-3)
+            assert sa == sb and abs(sa["loss"] - res["loss"]) <= 2e-5 * res["loss"]
+        pa = a.get_params_flat()
+        np.testing.assert_array_equal(pa, b.get_params_flat())
+        p0, ref = r.flatten(p, cfg), r.flatten(q, cfg)
+        d_got, d_ref = pa.astype(np.float64) - p0, ref - p0
+        assert np.linalg.norm(d_got - d_ref) <= 2e-3 * np.linalg.norm(d_ref)
+
+
+def test_real_mirror_class(T):
+    from imitation_from_observation_amd.arm_shaping import ContextAEReal
+    cfg, p, fr = make(36, 64, 2, seed=5)
+    model = ContextAEReal()
+    model.build((3, 2, 36, 64, 3))
+    model.translator.set_params(p)
+    tfeat, timg = model.run([model.translated_z, model.out], [fr[0], [fr[1][0]] * 2, [fr[1][0]] * 2])
+    assert tfeat.shape == (2, 100) and timg.shape == (2, 36, 64, 3)
+    model.translator.close()
