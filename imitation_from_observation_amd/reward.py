@@ -25,6 +25,20 @@ class TranslatorReward:
         self.skip = 2 if name in ("real", "sweep") else 1        # base.py:209-211
         self.means, self.imgs = None, None
 
+    @classmethod
+    def for_sampler(cls, name, imsize, nvp, scale, modelname=None, ablation_type="None", batch_size=25,
+                    paths_per_launch=10, device=0):
+        """What BaseSampler.initialize() sets up for mode 'ours' (base.py:113-145): the model class follows the
+        experiment name -- ContextAEReal for 'real'/'sweep', ContextSkipNew otherwise (:134-137) -- on the
+        sampler's imsize, restored from `modelname` when given (:138)."""
+        from .translator import Translator
+        real = name in ("real", "sweep")
+        tr = Translator(imsize[0], imsize[1], featsize=100 if real else 1024, max_batch=batch_size * paths_per_launch,
+                        device=device, variant="real" if real else "skipnew")
+        if modelname is not None:
+            tr.load(modelname)
+        return cls(tr, nvp, scale, name=name, ablation_type=ablation_type, batch_size=batch_size)
+
     # ------------------------------------------------------------------ base.py:195-223
     @staticmethod
     def _frames_of(path):

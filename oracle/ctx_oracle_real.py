@@ -184,3 +184,19 @@ def backward(p, c, cfg: RealConfig, sim_batch=None):
     encode_bwd(c["tgt"], c["e_tgt"], dtgt_z)
     encode_bwd(c["ctx"], c["e_ctx"], dtcat[:, F:], dskips=[a + b for a, b in zip(dsk1, dsk2)])
     return g
+
+
+def translate(p, src_u8, ctx0_u8, cfg: RealConfig):
+    """rllab/sampler/base.py:216-218 on ContextAEReal: feed [src, [ctx0]*B, [ctx0]*B], fetch (out, translated_z)."""
+    from .ctx_oracle import preprocess_u8
+    src = preprocess_u8(src_u8)
+    ctx = np.broadcast_to(preprocess_u8(ctx0_u8), src.shape)
+    res, _ = forward(p, src, ctx, ctx, cfg)
+    return res["out"], res["translated_z"]
+
+
+def encode(p, frames_u8, cfg: RealConfig):
+    """base.py:234-235: fetch (input_z, image_trans[0])."""
+    from .ctx_oracle import preprocess_u8
+    x = preprocess_u8(frames_u8)
+    return _encode(p, x)[5], x

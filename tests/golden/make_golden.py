@@ -86,7 +86,50 @@ def make(tag, cfg, B, pseed, stddev, frames, steps, lr=1e-4):
     print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
 
 
+def make_real(tag, cfg, B, pseed, stddev, frames, steps, lr=1e-4):
+    """Same contents for ContextAEReal (oracle/ctx_oracle_real.py)."""
+    from oracle import ctx_oracle_real as r
+    p = r.init_params(cfg, pseed, np.float64, stddev=stddev)
+    brng = np.random.default_rng(pseed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    su8, cu8, tu8 = (frames(s, B, cfg.H, cfg.W) for s in (0, 1, 2))
+    src, ctx, tgt = (o.preprocess_u8(x).astype(np.float64) for x in (su8, cu8, tu8))
+    fx = dict(cfg=np.array([cfg.H, cfg.W, cfg.C, cfg.featsize]), B=B, pseed=pseed, stddev=stddev,
+              src_u8=su8, ctx_u8=cu8, tgt_u8=tu8, lr=lr, steps=steps)
+    fx["param_digest"], _ = digest(r.flatten(p, cfg))
+    res, c = r.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        fx[k] = res[k].astype(np.float32)
+    fx["scalars"] = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]])
+    g = r.backward(p, c, cfg)
+    names = [n for n, _ in r.param_specs(cfg)]
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_head"] = np.stack([np.pad(digest(g[n])[1], (0, N_HEAD - min(N_HEAD, g[n].size))) for n in names])
+    pred, feat = r.translate(p, su8, cu8[0], cfg)
+    fx["translate_pred"], fx["translate_feat"] = pred.astype(np.float32), feat.astype(np.float32)
+    fx["encode_feat"] = r.encode(p, su8, cfg)[0].astype(np.float32)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    traj, p0 = [], r.flatten(p, cfg)
+    for t in range(1, steps + 1):
+        rr, cc = r.forward(p, src, ctx, tgt, cfg)
+        o.adam_step(p, r.backward(p, cc, cfg), m, v, t, lr)
+        traj.append([rr["loss"], rr["simloss"], rr["recon1"], rr["recon2"]])
+    fx["train_scalars"] = np.array(traj)
+    delta = r.flatten(p, cfg) - p0
+    fx["delta_digest"] = np.stack([digest(dd)[0] for dd in np.split(delta, np.cumsum(
+        [int(np.prod(s)) for _, s in r.param_specs(cfg)])[:-1])])
+    path = os.path.join(HERE, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
+
+
 if __name__ == "__main__":
+    from oracle import ctx_oracle_real as r
+    # ContextAEReal at the reference's sweep imsize (run_trpo_sweep_ours.py:64)
+    make_real("real_f100_36x64_b3", r.RealConfig(), 3, 4321, 0.05, blob_frames, steps=3)
     # reduced net the HIP kernels accept (channels multiples of 32), iid frames
     make("skipnew_d32_f128_32x32_b4", o.SkipNewConfig(H=32, W=32, df_dim=32, gf_dim=32, featsize=128), 4, 1234, 0.05,
          synth_frames, steps=3)

@@ -104,3 +104,33 @@ def test_real_mirror_class(T):
     tfeat, timg = model.run([model.translated_z, model.out], [fr[0], [fr[1][0]] * 2, [fr[1][0]] * 2])
     assert tfeat.shape == (2, 100) and timg.shape == (2, 36, 64, 3)
     model.translator.close()
+
+
+def test_real_golden_vectors(T):
+    """HIP path vs the committed ContextAEReal fixture (tests/golden/make_golden.py:make_real)."""
+    from tests.test_oracle_real import _load_real_golden
+    z, cfg, p = _load_real_golden()
+    B = int(z["B"])
+    names = [n for n, _ in r.param_specs(cfg)]
+    with T(cfg.H, cfg.W, featsize=cfg.featsize, max_batch=B, variant="real") as tr:
+        tr.set_params(p)
+        pred, feat = tr.translate(z["src_u8"], z["ctx_u8"][0])
+        assert relmax(pred, z["translate_pred"]) < 1e-5 and relmax(feat, z["translate_feat"]) < 1e-5
+        assert relmax(tr.encode(z["src_u8"])[0], z["encode_feat"]) < 1e-5
+        ev = tr.evaluate(*(o.preprocess_u8(z[k]) for k in ("src_u8", "ctx_u8", "tgt_u8")))
+        for k in ("out", "out2"):
+            assert relmax(ev[k], z[k]) < 1e-5, k
+        for i, k in enumerate(("loss", "simloss", "recon1", "recon2")):
+            assert abs(ev[k] - z["scalars"][i]) <= 1e-5 * abs(z["scalars"][i])
+        for t in range(int(z["steps"])):
+            sc = tr.train_step_u8(z["src_u8"], z["ctx_u8"], z["tgt_u8"], lr=float(z["lr"]))
+            if t == 0:
+                g = tr.get_grads()
+                for i, n in enumerate(names):
+                    a = np.asarray(g[n], np.float64).reshape(-1)
+                    got = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())])
+                    ref = z["grad_digest"][i]
+                    assert abs(got[2] - ref[2]) <= 1e-4 * ref[2] and abs(got[1] - ref[1]) <= 1e-4 * ref[1], n
+                    h = min(64, a.size)
+                    assert np.abs(a[:h] - z["grad_head"][i][:h]).max() <= 1e-4 * np.abs(a).max() + 1e-12, n
+            np.testing.assert_allclose(sc["loss"], z["train_scalars"][t][0], rtol=2e-5)

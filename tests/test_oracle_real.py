@@ -70,3 +70,31 @@ def test_real_oracle_matches_torch_autograd(H, W, B):
     for k in g:
         tg = tp[k].grad.numpy()
         assert np.abs(g[k] - tg).max() <= 1e-9 * (np.abs(tg).max() + 1e-30), k
+
+
+def _load_real_golden():
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "real_f100_36x64_b3.npz"))
+    H, W, C, F = (int(v) for v in z["cfg"])
+    cfg = r.RealConfig(H=H, W=W, C=C, featsize=F)
+    p = r.init_params(cfg, int(z["pseed"]), np.float64, stddev=float(z["stddev"]))
+    brng = np.random.default_rng(int(z["pseed"]) + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * float(z["stddev"])
+    return z, cfg, p
+
+
+def test_oracle_reproduces_real_golden():
+    from oracle import ctx_oracle as o
+    z, cfg, p = _load_real_golden()
+    dg = lambda a: np.array([np.sum(a), np.abs(a).sum(), np.sqrt((np.asarray(a, np.float64) ** 2).sum())])
+    np.testing.assert_allclose(dg(r.flatten(p, cfg)), z["param_digest"], rtol=1e-12)
+    src, ctx, tgt = (o.preprocess_u8(z[k]).astype(np.float64) for k in ("src_u8", "ctx_u8", "tgt_u8"))
+    res, c = r.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        np.testing.assert_allclose(res[k], z[k], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([res["loss"], res["simloss"], res["recon1"], res["recon2"]], z["scalars"], rtol=1e-12)
+    g = r.backward(p, c, cfg)
+    for i, (n, _) in enumerate(r.param_specs(cfg)):
+        np.testing.assert_allclose(dg(g[n]), z["grad_digest"][i], rtol=1e-9, atol=1e-12)

@@ -178,3 +178,40 @@ def test_arm_shaping_mirror_fetches():
     with pytest.raises(ValueError):
         ContextSkipNew(gf_dim=32)
     model.translator.close()
+
+
+@pytest.mark.gpu
+def test_sweep_hook_uses_context_ae_real_on_36x64():
+    """name 'sweep' -> ContextAEReal at imsize (36, 64), every other demo frame (base.py:134-135, 209-211)."""
+    import copy
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ctx_oracle_real as r
+    cfg = r.RealConfig()
+    p = r.init_params(cfg, 8, np.float32, stddev=0.1)
+    rng = np.random.default_rng(9)
+    validdata = rng.uniform(-1, 1, (50, 4, 36, 64, 3)).astype(np.float32)
+    paths = []
+    for _ in range(3):
+        imgs = [None if t % 2 == 0 else [rng.integers(0, 256, (36, 64, 3), dtype=np.uint8)] for t in range(50)]
+        paths.append({"rewards": rng.standard_normal(50), "env_infos": {"imgs": imgs}})
+    first = paths[0]["env_infos"]["imgs"][1]
+
+    class RealOracleTranslator:
+        max_batch, H, W, featsize = 50, 36, 64, 100
+        def translate(self, src, ctx0):
+            return r.translate(p, src, ctx0, cfg)
+        def encode(self, frames, return_frames=True):
+            return r.encode(p, frames, cfg)
+
+    paths2 = copy.deepcopy(paths)
+    cref = TranslatorReward(RealOracleTranslator(), 1, 0.01, name="sweep").build_demo_cache(validdata, first).process_paths(paths)
+    hook = TranslatorReward.for_sampler("sweep", (36, 64), nvp=1, scale=0.01, paths_per_launch=2)
+    assert hook.tr.variant == "real" and hook.skip == 2 and hook.tr.featsize == 100
+    hook.tr.set_params(p)
+    c = hook.build_demo_cache(validdata, first).process_paths(paths2)
+    hook.tr.close()
+    np.testing.assert_allclose(c, cref, rtol=1e-3)
+    for a, b in zip(paths2, paths):
+        np.testing.assert_allclose(a["rewards"], b["rewards"], rtol=1e-3, atol=1e-5)
