@@ -28,6 +28,7 @@ BYTES_PER_TRIPLE = 15_155_200
 BYTES_PER_STEP_FIXED = 1_905_912_440
 PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_HBM = 8.0e12
+PEAK_BF16_MFMA = 2.5e15                            # dense; a split product costs 3 bf16 MFMA flops per algorithmic flop
 
 
 def cpu_baseline(batch, steps):
@@ -68,6 +69,10 @@ def main():
     ap.add_argument("--kernel-iters", type=int, default=5)
     ap.add_argument("--host-buffers", action="store_true",
                     help="also time ctx_train_step on host (numpy) frames: the PCIe-inclusive rate quoted in DESIGN.md")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default=os.environ.get("CTX_PRECISION", "f32"),
+                    help="arithmetic of the contractions: exact f32 MFMA (default) or split-bf16 products (DESIGN.md section 6b)")
+    ap.add_argument("--no-split-leg", action="store_true",
+                    help="skip the extra bf16x3 measurement that a default (f32) run appends as line['bf16x3']")
     args = ap.parse_args()
 
     import torch
@@ -86,7 +91,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = args.batch
-    trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234)
+    trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision=args.precision)
     g = torch.Generator(device="cuda").manual_seed(100 + rank)
     frames = [torch.randint(0, 256, (B, H, W, 3), device="cuda", generator=g, dtype=torch.uint8) for _ in range(3)]
     src, ctx, tgt = (f.float() / 127.5 - 1.0 for f in frames)      # synthetic frames, train_script.py:16-19 scaling
@@ -96,19 +101,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(src, ctx, tgt, lr=1e-4)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.step(src, ctx, tgt, lr=1e-4)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    scal = trainer.scalars()
+    def timed(tr_):
+        for _ in range(args.warmup):
+            tr_.step(src, ctx, tgt, lr=1e-4)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr_.step(src, ctx, tgt, lr=1e-4)
+        barrier()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt_], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_ = float(tmax.item())
+        return dt_, tr_.scalars()
+
+    dt, scal = timed(trainer)
 
     ms = 1e3 * dt / args.steps
     value = args.steps * B * world / dt
@@ -116,8 +124,10 @@ def main():
         "metric": "frames/sec fwd+bwd+Adam, 64x64x3, batch 256 per GPU",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "ContextSkipNew 64x64x3 fwd+bwd+Adam, batch 256/GPU (BASELINE configs[1])",
+                   "precision": ("exact f32 MFMA" if args.precision == "f32" else
+                                 "split-bf16: a*b = hi*hi + hi*lo + lo*hi on bf16 MFMA, f32 accumulate; f32 everywhere else"),
                    "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
                    "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
         "loss_after": scal["loss"],
@@ -136,15 +146,18 @@ def main():
         kname, k = next(iter(tab.items()))          # the kernel with the most time in a step
         per_launch_ms = k["ms"] / k["launches"]
         ach = k["flops"] / (k["ms"] * 1e-3)
-        line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                            "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "launches_per_step": k["launches"],
+        # f32: algorithmic flops against the f32-MFMA peak.  bf16x3: every algorithmic flop is 3 bf16 MFMA flops, so the
+        # algorithmic rate is priced against (dense bf16 peak) / 3.
+        peak = PEAK_F32_MFMA if args.precision == "f32" else PEAK_BF16_MFMA / 3
+        line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach / 1e12, "peak": peak / 1e12,
+                            "unit": "TFLOP/s", "frac": ach / peak, "launches_per_step": k["launches"],
                             "avg_ms_per_launch": per_launch_ms, "flops_per_launch": k["flops"] / k["launches"],
                             "share_of_step_ms": k["ms"] / sum(t["ms"] for t in tab.values()), "traffic": None}
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
         # figure comes from the committed rocprofv3 --pmc passes of the same workload (profiles/*_hbm_traffic.json)
         import glob
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-        if prof and B == 256:
+        if prof and B == 256 and args.precision == "f32":
             with open(prof[-1]) as f:
                 tr_json = json.load(f)
             ent = tr_json["per_kernel"].get(kname)
@@ -166,6 +179,17 @@ def main():
             for _ in range(5):
                 tr.train_step(hs, hc, ht, lr=1e-4)
             line["host_buffer_frames_per_s"] = 5 * B / (time.perf_counter() - t0)
+        if args.precision == "f32" and not args.no_split_leg and world == 1:
+            # the same workload with split-bf16 products (CTX_PREC_BF16X3): reported beside, never as `value`
+            del trainer
+            t2 = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision="bf16x3")
+            dt2, scal2 = timed(t2)
+            line["bf16x3"] = {"value": args.steps * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                              "tflops_algorithmic": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt2 / args.steps) / 1e12,
+                              "loss_after": scal2["loss"], "loss_rel_diff_vs_f32": abs(scal2["loss"] - scal["loss"]) / abs(scal["loss"]),
+                              "note": "products a*b evaluated as hi*hi + hi*lo + lo*hi on bf16 MFMA with f32 accumulation "
+                                      "(~1e-5 relative, tests/test_gpu_split.py); everything else f32"}
+            del t2
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(batch=32, steps=3)
         print(json.dumps(line), flush=True)

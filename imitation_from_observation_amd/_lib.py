@@ -9,10 +9,12 @@ LIB_PATH = os.path.join(_HERE, "libctxtrans.so")
 CTX_OK, CTX_E_INVALID, CTX_E_DEVICE, CTX_E_NOMEM, CTX_E_STATE = 0, -1, -2, -3, -4
 CTX_VARIANT_SKIPNEW = 0
 CTX_VARIANT_REAL = 1
+CTX_PREC_F32 = 0
+CTX_PREC_BF16X3 = 1
 
 
 class CtxConfig(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("variant", "H", "W", "C", "df_dim", "featsize", "max_batch", "reserved")]
+    _fields_ = [(n, ctypes.c_int32) for n in ("variant", "H", "W", "C", "df_dim", "featsize", "max_batch", "precision")]
 
 
 class CtxProfEntry(ctypes.Structure):

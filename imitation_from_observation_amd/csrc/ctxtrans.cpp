@@ -165,6 +165,7 @@ int check_cfg(const ctx_config* c, ctx_handle* h) {
     if (c->variant != CTX_VARIANT_SKIPNEW && c->variant != CTX_VARIANT_REAL)
         return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
     if (c->C != 3) return fail(h, CTX_E_INVALID, "C must be 3");
+    if (c->precision != CTX_PREC_F32 && c->precision != CTX_PREC_BF16X3) return fail(h, CTX_E_INVALID, "unsupported precision %d", c->precision);
     if (c->variant == CTX_VARIANT_REAL) {   // ContextAEReal: two stride-2 layers, fixed filters 32/16/16/8
         if (c->H <= 0 || c->W <= 0 || c->H % 4 || c->W % 4) return fail(h, CTX_E_INVALID, "H, W must be positive multiples of 4 (got %dx%d)", c->H, c->W);
         if (c->featsize <= 0 || c->featsize % 4) return fail(h, CTX_E_INVALID, "featsize must be a multiple of 4");
@@ -295,7 +296,7 @@ int alloc_buffers(ctx_handle* h) {
     return CTX_OK;
 }
 
-SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats}; }
+SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.precision}; }
 
 // Everything below enqueues on h->stream with h->slab / h->scratch; LaneSwap points those at the second lane
 // for the lifetime of a scope.  fork(): the second lane starts after everything enqueued so far on the

@@ -4,13 +4,29 @@
 #include <cstdlib>
 
 #include "launch.h"
+#include "igemm_split.h"
 
 namespace ctx {
 
 void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);
 
 template <class LA, class LB, int MI, int NI, int WM, int WN>
-static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+    constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
+    constexpr size_t lds = 2 * (size_t)(STile<LA::KM, TM, NT>::FLOATS + STile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
+    static bool raised = false;
+    if (lds > 65536 && !raised) {
+        (void)hipFuncSetAttribute((const void*)igemm_split_kernel<LA, LB, MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        raised = true;
+    }
+    const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
+    dim3 grid((unsigned)((int64_t)gm * gn * nprob * nsplit));
+    hipLaunchKernelGGL((igemm_split_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
+}
+
+template <class LA, class LB, int MI, int NI, int WM, int WN>
+static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit, int prec = 0) {
+    if (prec) { launch_tile_split<LA, LB, MI, NI, WM, WN>(s, a, b, ep, M, N, nprob, nsplit); return; }
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
     constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM, NT>::FLOATS + Tile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
@@ -33,7 +49,7 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
         if (force != 1 && M >= 256 && N >= 256 && (big_tiles >= 192 || force == 2)) {
             ep.slab = nullptr;
-            launch_tile<LA, LB, 2, 4, 4, 2>(s, a, b, ep, M, N, nprob, 1);
+            launch_tile<LA, LB, 2, 4, 4, 2>(s, a, b, ep, M, N, nprob, 1, ws.prec);
             return;
         }
     }
@@ -45,11 +61,14 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     // count is chosen to minimise  rounds * (chunks per block + fixed cost)  + slab write/read time.
     int nsplit = 1;
     if (min_chunks >= 8 && ws.slab) {
-        const size_t lds = 2 * (size_t)((LA::KM ? 64 * MI * LDK : KC * 64 * MI) + (LB::KM ? 64 * NI * LDK : KC * 64 * NI)) * sizeof(float);
+        const size_t lds = ws.prec ? 2 * (size_t)(64 * MI + 64 * NI) * SLDR * sizeof(float)
+                                   : 2 * (size_t)((LA::KM ? 64 * MI * LDK : KC * 64 * MI) + (LB::KM ? 64 * NI * LDK : KC * 64 * NI)) * sizeof(float);
         int occ = (int)(160 * 1024 / lds);
         if (occ > (MI * NI == 4 ? 2 : 4)) occ = MI * NI == 4 ? 2 : 4;            // register-file limit
         const double slots = 256.0 * occ;
-        const double t_chunk = 16.0 * MI * NI * 64.0 * occ / 2.3e9;             // `occ` waves share each SIMD's matrix pipe
+        // `occ` waves share each SIMD's matrix pipe; the split-bf16 chunk is 6 x 32 cycles per 32x32 tile but
+        // runs at about half the pipe rate (conversion + LDS traffic), so ~1/3 of the f32 chunk
+        const double t_chunk = 16.0 * MI * NI * 64.0 * occ / 2.3e9 * (ws.prec ? 0.35 : 1.0);
         const int64_t cap_ws = ws.slab_floats / ((int64_t)nprob * M * N);
         double best = 1e30;
         for (int n = 1; n <= 256 && n <= min_chunks / 4 && (n == 1 || n <= cap_ws); ++n) {
@@ -60,10 +79,10 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
-    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
-    else if (MI == 2) launch_tile<LA, LB, 2, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
-    else if (NI == 2) launch_tile<LA, LB, 1, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
-    else launch_tile<LA, LB, 1, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
+    else if (MI == 2) launch_tile<LA, LB, 2, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
+    else if (NI == 2) launch_tile<LA, LB, 1, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
+    else launch_tile<LA, LB, 1, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
     if (nsplit > 1) splitk_reduce(s, ep, M, N, nprob, nsplit);
 }
 

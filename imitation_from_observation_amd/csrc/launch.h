@@ -12,6 +12,7 @@ namespace ctx {
 struct SplitWs {
     float* slab;
     int64_t slab_floats;
+    int prec = 0;   // CTX_PREC_*: 0 exact-f32 MFMA, 1 split-bf16 (igemm_split.h)
 };
 
 // Each launcher computes D = A*B through igemm_kernel with the given loader pair; nprob problems

@@ -30,7 +30,7 @@ class HipEngine:
     and owns the stream, libctxtrans enqueues its kernels on that stream, so RCCL calls issued through
     torch.distributed are stream-ordered with them."""
 
-    def __init__(self, H, W, df_dim, featsize, max_batch, device, seed):
+    def __init__(self, H, W, df_dim, featsize, max_batch, device, seed, precision=None):
         self.dev = torch.device("cuda", device)
         n = Translator.arena_floats(H, W, df_dim, featsize)
         self.arena = torch.zeros(n, device=self.dev, dtype=torch.float32)
@@ -39,7 +39,7 @@ class HipEngine:
         # a dedicated torch stream (the legacy default stream has handle 0 = "make your own" in the C ABI)
         self.stream = torch.cuda.Stream(self.dev)
         self.translator = Translator(H, W, df_dim, featsize, max_batch, device=device,
-                                     stream=self.stream.cuda_stream, arena_ptr=self.arena.data_ptr())
+                                     stream=self.stream.cuda_stream, arena_ptr=self.arena.data_ptr(), precision=precision)
         self.translator.init_params(seed)
         self.n_params = self.translator.n_params
         self.params = self.arena[: self.stride]
@@ -67,8 +67,8 @@ class HipEngine:
 
 
 class DataParallelTrainer:
-    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, seed=1234, engine=None):
-        self.engine = engine or HipEngine(H, W, df_dim, featsize, max_batch, device, seed)
+    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, seed=1234, engine=None, precision=None):
+        self.engine = engine or HipEngine(H, W, df_dim, featsize, max_batch, device, seed, precision)
         self.world = _world()
         self.n_params = self.engine.n_params
         if self.world > 1:

@@ -9,6 +9,7 @@ happens in the HIP kernels; this file only moves numpy buffers across the C ABI.
 from __future__ import annotations
 
 import ctypes
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -52,14 +53,16 @@ class Translator:
     """
 
     VARIANTS = {"skipnew": _lib.CTX_VARIANT_SKIPNEW, "real": _lib.CTX_VARIANT_REAL}
+    PRECISIONS = {"f32": _lib.CTX_PREC_F32, "bf16x3": _lib.CTX_PREC_BF16X3}
 
     def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None,
-                 variant="skipnew"):
+                 variant="skipnew", precision=None):
         """variant "skipnew": ContextSkipNew (sampler names push/reach/strike/throw); "real": ContextAEReal
         (names real/sweep; pass H=36, W=64, featsize=100 -- df_dim is ignored, rllab/sampler/base.py:134-137)."""
+        precision = precision or os.environ.get("CTX_PRECISION", "f32")     # "f32" (exact) | "bf16x3" (split-bf16 products)
         self._lib = _lib.load()
-        self.variant = variant
-        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, 3, df_dim, featsize, max_batch, 0)
+        self.variant, self.precision = variant, precision
+        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, 3, df_dim, featsize, max_batch, self.PRECISIONS[precision])
         self.H, self.W, self.df_dim, self.featsize, self.max_batch = H, W, df_dim, featsize, max_batch
         self.device = device
         self._h = ctypes.c_void_p()

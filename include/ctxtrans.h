@@ -56,6 +56,14 @@ enum {
                                 a multiple of 4, df_dim ignored, keep_prob = 1 */
 };
 
+/* Arithmetic of the convolutions / linear layers (everything else -- epilogues, losses, reductions, Adam,
+ * parameters, activations in HBM -- is f32 in both modes):
+ *   CTX_PREC_F32     v_mfma_f32_32x32x2_f32: bitwise an fmaf chain.
+ *   CTX_PREC_BF16X3  every f32 operand is split on the fly into bf16 hi + bf16 lo and a*b is evaluated as
+ *                    hi*hi + hi*lo + lo*hi on the bf16 matrix cores with f32 accumulation: ~2^-16 relative error
+ *                    per product, inside the 1e-3 budget of the path, at 16/3 the f32 matrix rate. */
+enum { CTX_PREC_F32 = 0, CTX_PREC_BF16X3 = 1 };
+
 typedef struct ctx_config {
     int32_t variant;    /* CTX_VARIANT_* */
     int32_t H, W, C;    /* frame size; H, W multiples of 16 (arm_shaping.py:1314-1319); C == 3 */
@@ -63,7 +71,7 @@ typedef struct ctx_config {
                            multiple of 32 */
     int32_t featsize;   /* 1024 in the reference (arm_shaping.py:1277); multiple of 32 */
     int32_t max_batch;  /* largest B any later call will pass */
-    int32_t reserved;
+    int32_t precision;  /* CTX_PREC_*: arithmetic of the matrix contractions (0 = exact f32, the default) */
 } ctx_config;
 
 typedef struct ctx_handle ctx_handle;
