@@ -106,3 +106,68 @@ def forward_real(p, src, ctx, tgt, H, W):
     r1 = 0.5 * ((tgt - out) ** 2).sum()
     r2 = 0.5 * ((tgt - out2) ** 2).sum()
     return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1, recon2=r2, loss=r1 + r2 + sim)
+
+
+def tf_same(n, k, s):
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2, total - total // 2
+
+
+def tf_conv_ks(x_nhwc, w_hwio, b, s):
+    """tf.nn.conv2d, SAME, any kernel size / stride / grid (incl. 1x1 grids under stride 2)."""
+    k = w_hwio.shape[0]
+    x = x_nhwc.permute(0, 3, 1, 2)
+    _, pt, pb = tf_same(x.shape[2], k, s)
+    _, pl, pr = tf_same(x.shape[3], k, s)
+    y = F.conv2d(F.pad(x, (pl, pr, pt, pb)), w_hwio.permute(3, 2, 0, 1), b, stride=s)
+    return y.permute(0, 2, 3, 1)
+
+
+def tf_deconv_ks(x_nhwc, w_hwoi, b, out_hw, s):
+    """tf.nn.conv2d_transpose, SAME, output_shape given: full transposed conv, cropped at the SAME pad_before of the
+    forward conv over the OUTPUT grid."""
+    k = w_hwoi.shape[0]
+    x = x_nhwc.permute(0, 3, 1, 2)
+    _, pt, _ = tf_same(out_hw[0], k, s)
+    _, pl, _ = tf_same(out_hw[1], k, s)
+    full = F.conv_transpose2d(x, w_hwoi.permute(3, 2, 0, 1), None, stride=s, padding=0)
+    need_h, need_w = pt + out_hw[0], pl + out_hw[1]
+    full = F.pad(full, (0, max(0, need_w - full.shape[3]), 0, max(0, need_h - full.shape[2])))
+    y = full[:, :, pt:need_h, pl:need_w] + b.view(1, -1, 1, 1)
+    return y.permute(0, 2, 3, 1)
+
+
+def forward_incep2(p, src, ctx, tgt, H, W, strides, filters):
+    """arm_shaping.py:1792-1894 through torch ops + autograd."""
+    sizes, h, w = [], H, W
+    for s in strides:
+        h, w = -(-h // s), -(-w // s)
+        sizes.append((h, w))
+
+    def enc(scope, img):
+        acts, hh = [], img
+        for k in range(4):
+            hh = lrelu(tf_conv_ks(hh, p[f"{scope}/h{k}_conv/w"], p[f"{scope}/h{k}_conv/biases"], strides[k]))
+            acts.append(hh)
+        h4 = lrelu(hh.reshape(hh.shape[0], -1) @ p[f"{scope}/h4_lin/Matrix"] + p[f"{scope}/h4_lin/bias"])
+        return acts, lrelu(h4 @ p[f"{scope}/hz_lin/Matrix"] + p[f"{scope}/hz_lin/bias"])
+
+    def dec(z, skips):
+        hh = lrelu(z @ p["deconv/d_h0_lin/Matrix"] + p["deconv/d_h0_lin/bias"]).reshape(-1, sizes[3][0], sizes[3][1], filters[3])
+        outs = [sizes[2], sizes[1], sizes[0], (H, W)]
+        for k in range(1, 5):
+            hh = tf_deconv_ks(torch.cat([hh, skips[4 - k]], 3), p[f"deconv/d_h{k}/w"], p[f"deconv/d_h{k}/biases"], outs[k - 1], strides[4 - k])
+            if k < 4:
+                hh = lrelu(hh)
+        return hh
+
+    skips, ctx_z = enc("conv_context", ctx)
+    _, src_z = enc("conv", src)
+    _, tgt_z = enc("conv", tgt)
+    th0 = lrelu(torch.cat([src_z, ctx_z], 1) @ p["translate/trans_h0/Matrix"] + p["translate/trans_h0/bias"])
+    trans_z = th0 @ p["translate/trans_z/Matrix"] + p["translate/trans_z/bias"]
+    out, out2 = dec(trans_z, skips) + ctx, dec(tgt_z, skips) + ctx
+    sim = ((trans_z - tgt_z) ** 2).mean() * 1e3
+    r1, r2 = 0.5 * ((tgt - out) ** 2).sum(), 0.5 * ((tgt - out2) ** 2).sum()
+    return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1, recon2=r2, loss=r1 + r2 + sim)
