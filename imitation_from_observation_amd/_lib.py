@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libctxtrans.so")
 CTX_OK, CTX_E_INVALID, CTX_E_DEVICE, CTX_E_NOMEM, CTX_E_STATE = 0, -1, -2, -3, -4
 CTX_VARIANT_SKIPNEW = 0
 CTX_VARIANT_REAL = 1
+CTX_VARIANT_INCEPTION2 = 2
 CTX_PREC_F32 = 0
 CTX_PREC_BF16X3 = 1
 
@@ -55,6 +56,8 @@ SIGNATURES = {
     "ctx_init_params": (_c.c_int, [_P, _c.c_uint64]),
     "ctx_translate": (_c.c_int, [_P, _U8, _U8, _c.c_int, _c.c_int, _F, _F]),
     "ctx_encode": (_c.c_int, [_P, _U8, _c.c_int, _F, _F]),
+    "ctx_translate_f32": (_c.c_int, [_P, _F, _F, _c.c_int, _c.c_int, _F, _F]),
+    "ctx_encode_f32": (_c.c_int, [_P, _F, _c.c_int, _F]),
     "ctx_train_step": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _c.c_float, _F]),
     "ctx_train_step_u8": (_c.c_int, [_P, _U8, _U8, _U8, _c.c_int, _c.c_float, _F]),
     "ctx_demos_upload": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),

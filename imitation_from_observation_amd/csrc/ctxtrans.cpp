@@ -46,11 +46,11 @@ struct ParamInfo {
 
 }  // namespace
 
-namespace { struct RealState; }
+namespace { struct GenState; }
 
 struct ctx_handle {
     ctx_config cfg{};
-    RealState* real = nullptr;   // CTX_VARIANT_REAL state (ctxtrans_real.inc)
+    GenState* gen = nullptr;     // CTX_VARIANT_REAL / CTX_VARIANT_INCEPTION2 state (ctxtrans_gen.inc)
     int Fp = 0;                  // row stride of the code buffers Z / dZ (featsize, or featsize padded to 32 for REAL)
     int device = 0;
     hipStream_t stream = nullptr;
@@ -162,8 +162,22 @@ struct ProfScope {
 
 int check_cfg(const ctx_config* c, ctx_handle* h) {
     if (!c) return fail(h, CTX_E_INVALID, "cfg is NULL");
-    if (c->variant != CTX_VARIANT_SKIPNEW && c->variant != CTX_VARIANT_REAL)
+    if (c->variant != CTX_VARIANT_SKIPNEW && c->variant != CTX_VARIANT_REAL && c->variant != CTX_VARIANT_INCEPTION2)
         return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
+    if (c->variant == CTX_VARIANT_INCEPTION2) {   // feature maps [h, w, C], filters 16d/16d/8d/8d, k 3, strides 1/2/1/2
+        if (c->C <= 0 || c->C % 32) return fail(h, CTX_E_INVALID, "C (feature channels) must be a positive multiple of 32");
+        if (c->df_dim <= 0 || c->df_dim % 4) return fail(h, CTX_E_INVALID, "df_dim must be a multiple of 4 (filters 16d/16d/8d/8d)");
+        if (c->featsize <= 0 || c->featsize % 32) return fail(h, CTX_E_INVALID, "featsize must be a multiple of 32");
+        if (c->H <= 0 || c->W <= 0 || c->max_batch <= 0) return fail(h, CTX_E_INVALID, "H, W, max_batch must be positive");
+        int hc = c->H, wc = c->W;
+        for (int k = 0; k < 4; ++k) {
+            const int s = (k & 1) && !(hc == 1 && wc == 1) ? 2 : 1;
+            if (hc % s || wc % s) return fail(h, CTX_E_INVALID, "feature grid %dx%d: a stride-2 layer meets an odd grid larger than 1x1", c->H, c->W);
+            hc /= s; wc /= s;
+        }
+        if (c->precision != CTX_PREC_F32 && c->precision != CTX_PREC_BF16X3) return fail(h, CTX_E_INVALID, "unsupported precision %d", c->precision);
+        return CTX_OK;
+    }
     if (c->C != 3) return fail(h, CTX_E_INVALID, "C must be 3");
     if (c->precision != CTX_PREC_F32 && c->precision != CTX_PREC_BF16X3) return fail(h, CTX_E_INVALID, "unsupported precision %d", c->precision);
     if (c->variant == CTX_VARIANT_REAL) {   // ContextAEReal: two stride-2 layers, fixed filters 32/16/16/8
@@ -440,14 +454,14 @@ void encoder_fwd(ctx_handle* h, const std::string& scn, const Scope& sc, const f
 enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
 
 }  // namespace
-#include "ctxtrans_real.inc"
+#include "ctxtrans_gen.inc"
 namespace {
 
 // Forward.  TRAIN/EVAL: st = [tgt | src] (2B), decoder = [translated | truth] (2B).
 // TRANSLATE: only what translated_z / out depend on (src encoder, ctx encoder, translate, decoder
 // pass 1) -- the subgraph TF would run for base.py:216-218.  ENCODE: `conv` encoder on src only.
 void forward(ctx_handle* h, int B, Mode mode) {
-    if (h->real) { real_forward(h, B, mode); return; }
+    if (h->gen) { gen_forward(h, B, mode); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
@@ -502,7 +516,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
 // d loss / d params into the grad arena (what AdamOptimizer.minimize differentiates,
 // scripts/train_script.py:128).  Every gradient tensor is written exactly once.
 void backward(ctx_handle* h, int B, int sim_batch) {
-    if (h->real) { real_backward(h, B, sim_batch); return; }
+    if (h->gen) { gen_backward(h, B, sim_batch); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
     const int64_t npi = h->npi;
@@ -686,21 +700,21 @@ int64_t ctx_param_total_for(const ctx_config* cfg) {
     if (check_cfg(cfg, nullptr) != CTX_OK) return CTX_E_INVALID;
     std::vector<ParamInfo> ps;
     int64_t total = 0;
-    if (cfg->variant == CTX_VARIANT_REAL) {
-        RealState r;
+    if (cfg->variant != CTX_VARIANT_SKIPNEW) {
+        GenState r;
         int64_t pp = 0;
-        real_layout(*cfg, r, ps, total, pp);
+        gen_layout(*cfg, r, ps, total, pp);
     } else build_params(*cfg, ps, total);
     return total;
 }
 
 int64_t ctx_arena_bytes(const ctx_config* cfg) {
     if (check_cfg(cfg, nullptr) != CTX_OK) return CTX_E_INVALID;
-    if (cfg->variant == CTX_VARIANT_REAL) {   // the arena holds the zero-padded parameters
-        RealState r;
+    if (cfg->variant != CTX_VARIANT_SKIPNEW) {   // the arena holds the zero-padded parameters
+        GenState r;
         std::vector<ParamInfo> ps;
         int64_t total = 0, pp = 0;
-        real_layout(*cfg, r, ps, total, pp);
+        gen_layout(*cfg, r, ps, total, pp);
         return 4 * pp * (int64_t)sizeof(float);
     }
     const int64_t p = ctx_param_total_for(cfg);
@@ -724,13 +738,13 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     h->device = device;
     h->H = cfg->H; h->W = cfg->W; h->d = cfg->df_dim; h->F = cfg->featsize; h->Bm = cfg->max_batch;
     for (int k = 0; k < 5; ++k) { h->hh[k] = cfg->H >> k; h->ww[k] = cfg->W >> k; }
-    h->npi = (int64_t)cfg->H * cfg->W * 3;
+    h->npi = (int64_t)cfg->H * cfg->W * cfg->C;
     h->D0 = (int64_t)8 * h->d * h->hh[4] * h->ww[4];
     h->Fp = h->F;
-    if (cfg->variant == CTX_VARIANT_REAL) {
-        h->real = new RealState();
-        real_layout(*cfg, *h->real, h->params, h->P, h->Ppad);
-        h->Fp = h->real->Fp;
+    if (cfg->variant != CTX_VARIANT_SKIPNEW) {
+        h->gen = new GenState();
+        gen_layout(*cfg, *h->gen, h->params, h->P, h->Ppad);
+        h->Fp = h->gen->Fp;
     } else {
         build_params(*cfg, h->params, h->P);
         h->Ppad = round_up(h->P, 64);
@@ -751,7 +765,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
             h->own_arena = true;
         }
     }
-    if (rc == CTX_OK) rc = h->real ? real_alloc(h) : alloc_buffers(h);
+    if (rc == CTX_OK) rc = h->gen ? gen_alloc(h) : alloc_buffers(h);
     if (rc == CTX_OK) {
         const char* ov = getenv("CTX_OVERLAP");
         h->overlap = !(ov && ov[0] == '0');
@@ -785,7 +799,7 @@ void ctx_destroy(ctx_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
-    delete h->real;
+    delete h->gen;
     for (int l = 0; l < ctx_handle::NLANE; ++l) {
         if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
         if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
@@ -815,17 +829,27 @@ static int arena_io(ctx_handle* h, int slot, float* host, const float* chost, si
     if ((int64_t)n != h->P) return fail(h, CTX_E_INVALID, "expected %lld floats, got %zu", (long long)h->P, n);
     HIP_TRY(h, hipSetDevice(h->device));
     float* dev = h->arena + slot * h->Ppad;
-    if (h->real) {   // scatter / gather between the TF-shaped vector and the zero-padded arena
+    if (h->gen) {   // scatter / gather between the TF-shaped vector and the (possibly zero-padded) arena
         std::vector<float> padded((size_t)h->Ppad, 0.f);
-        const std::vector<int32_t>& map = h->real->real2pad;
+        const std::vector<int32_t>& map = h->gen->real2pad;
+        if (!chost) {
+            HIP_TRY(h, hipMemcpyAsync(padded.data(), dev, padded.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+            TRY(finish(h));
+        }
+        for (const GenState::Seg& sg : h->gen->segs) {
+            if (sg.map0 < 0) {
+                if (chost) memcpy(padded.data() + sg.poff, chost + sg.roff, (size_t)sg.size * sizeof(float));
+                else memcpy(host + sg.roff, padded.data() + sg.poff, (size_t)sg.size * sizeof(float));
+            } else if (chost) {
+                for (int64_t i = 0; i < sg.size; ++i) padded[(size_t)map[(size_t)(sg.map0 + i)]] = chost[sg.roff + i];
+            } else {
+                for (int64_t i = 0; i < sg.size; ++i) host[sg.roff + i] = padded[(size_t)map[(size_t)(sg.map0 + i)]];
+            }
+        }
         if (chost) {
-            for (size_t i = 0; i < n; ++i) padded[(size_t)map[i]] = chost[i];
             HIP_TRY(h, hipMemcpyAsync(dev, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             return finish(h);
         }
-        HIP_TRY(h, hipMemcpyAsync(padded.data(), dev, padded.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        TRY(finish(h));
-        for (size_t i = 0; i < n; ++i) host[i] = padded[(size_t)map[i]];
         return CTX_OK;
     }
     if (chost) HIP_TRY(h, hipMemcpyAsync(dev, chost, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -874,8 +898,53 @@ int ctx_init_params(ctx_handle* h, uint64_t seed) {
     return finish(h);
 }
 
+static int translate_tail(ctx_handle* h, int B, float* pred, float* feat) {
+    forward(h, B, MODE_TRANSLATE);
+    if (pred) HIP_TRY(h, hipMemcpyAsync(pred, h->out, (size_t)B * h->npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z, h->Fp * sizeof(float), h->F * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
+// the same two fetches on float inputs: frames already in [-1, 1], or Inception feature maps (CTX_VARIANT_INCEPTION2)
+int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ctx_batched, int B, float* pred, float* feat) {
+    TRY(check_B(h, B));
+    if (!src || !ctx0) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t npi = h->npi;
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, src, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    for (int slot = 0; slot <= 2; slot += 2) {             // image[1] = image[2] = [context]*B (base.py:217-218)
+        float* dst = h->img + (int64_t)slot * B * npi;
+        if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, ctx0, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        else
+            for (int b = 0; b < B; ++b)
+                HIP_TRY(h, hipMemcpyAsync(dst + (int64_t)b * npi, ctx0, (size_t)npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    return translate_tail(h, B, pred, feat);
+}
+
+int ctx_encode_f32(ctx_handle* h, const float* frames, int B, float* feat) {
+    TRY(check_B(h, B));
+    if (!frames) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, frames, (size_t)B * h->npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    forward(h, B, MODE_ENCODE);
+    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
+static int need_frames(ctx_handle* h) {
+    if (h && h->cfg.variant == CTX_VARIANT_INCEPTION2)
+        return fail(h, CTX_E_INVALID, "uint8 frames need the Inception-v3 front end (not built): pass Mixed_7c feature maps to the _f32 entry points");
+    return CTX_OK;
+}
+
 int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ctx_batched, int B, float* pred, float* feat) {
     TRY(check_B(h, B));
+    TRY(need_frames(h));
     if (!src || !ctx0) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;
@@ -886,20 +955,16 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
     u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
     if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, B * npi);
     else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi, B);
-    if (h->real) {   // the shared encoder also runs on the tgt slot: image[2] = [context]*B there (base.py:217-218)
+    if (h->gen) {   // the table-driven engine runs the whole graph: image[2] = [context]*B there (base.py:217-218)
         if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img, B * npi);
         else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img, npi, B);
     }
-    forward(h, B, MODE_TRANSLATE);
-    if (pred) HIP_TRY(h, hipMemcpyAsync(pred, h->out, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z, h->Fp * sizeof(float), h->F * sizeof(float), B,
-                                         hipMemcpyDeviceToHost, h->stream));
-    h->last_B = 0;
-    return finish(h);
+    return translate_tail(h, B, pred, feat);
 }
 
 int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32) {
     TRY(check_B(h, B));
+    TRY(need_frames(h));
     if (!frames) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;

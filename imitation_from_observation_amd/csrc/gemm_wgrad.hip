@@ -3,7 +3,7 @@
 namespace ctx {
 void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, 25, (a.npix + KC - 1) / KC, ws);
+    launch_igemm(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
 }
 void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
@@ -19,7 +19,7 @@ void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Ep
 }
 void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, 25, (a.npix + KC - 1) / KC, ws);
+    launch_igemm(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
 }
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;

@@ -67,14 +67,18 @@ inline PixDiv make_pixdiv(int hs, int ws) {
     return PixDiv{ws, hs, sh(ws), sh(hs)};
 }
 
-// chunk -> (tap segment, channel-slice index) for "slice outer, taps inner" K order; ntap in {4,6,9,25}
+// chunk -> (tap segment, channel-slice index) for "slice outer, taps inner" K order; the usual ntap values
 // is matched to a literal so the division is a multiply-shift on the scalar unit
 __device__ __forceinline__ void tap_slice(int chunk, int ntap, int& seg, int& slice) {
     switch (ntap) {
+        case 1: slice = chunk; break;
+        case 2: slice = chunk >> 1; break;
+        case 3: slice = chunk / 3; break;
         case 4: slice = chunk >> 2; break;
         case 6: slice = chunk / 6; break;
         case 9: slice = chunk / 9; break;
-        default: slice = chunk / 25; break;
+        case 25: slice = chunk / 25; break;
+        default: slice = chunk / ntap; break;
     }
     seg = chunk - slice * ntap;
 }
@@ -98,6 +102,7 @@ struct Epi {
     const float* bias = nullptr;    // [N]
     const float* add1 = nullptr;    // same pixel mapping as out, own ld
     int64_t lda1 = 0;
+    int64_t add1_mod = 0;           // != 0: add1 has this many pixels and serves two row blocks (pix, pix - add1_mod)
     const float* add2 = nullptr;
     int64_t lda2 = 0;
     const float* mask = nullptr;    // saved lrelu OUTPUT; v *= (mask >= 0 ? 1 : 0.2) for n < nsplit
@@ -126,7 +131,7 @@ __device__ __forceinline__ bool epi_row(const Epi& e, int prob, int m, int64_t& 
 
 __device__ __forceinline__ void epi_store(const Epi& e, int prob, int64_t pix, int n, float v) {
     if (e.bias) v += e.bias[n];
-    if (e.add1) v += e.add1[pix * e.lda1 + n];
+    if (e.add1) v += e.add1[((e.add1_mod && pix >= e.add1_mod) ? pix - e.add1_mod : pix) * e.lda1 + n];
     if (e.add2) v += e.add2[pix * e.lda2 + n];
     if (e.lrelu) v = fmaxf(v, LEAK * v);
     if (n < e.nsplit) {
@@ -207,14 +212,15 @@ struct KmConvGather {
     int tap_outer = 0;             // K order: 0 = channel slice outer / taps inner, 1 = taps outer
     int s = 2, pad = 1, flip = 0;
     const float* x2 = nullptr; int64_t ldx2 = 0; int c1 = 1 << 30; int nmod2 = 1;
+    int K = 5;                     // kernel size (5: ContextSkipNew / ContextAEReal, 3: ContextAEInception2)
     struct Pos { rsrc_t rs; int seg; bool second; };
     struct Ctx { uint32_t v, v2; unsigned mask; };   // v -> input pixel (s*i, s*j); mask bit = tap valid
-    __device__ int nchunks_of(int) const { return 25 * cps; }
+    __device__ int nchunks_of(int) const { return K * K * cps; }
     __device__ Pos pos(int, int chunk) const {
         int seg, slice;
         if (tap_outer) { seg = chunk / cps; slice = chunk - seg * cps; }
-        else tap_slice(chunk, 25, seg, slice);
-        const int ky = seg / 5, kx = seg - ky * 5;
+        else tap_slice(chunk, K * K, seg, slice);
+        const int ky = K == 5 ? seg / 5 : seg / K, kx = seg - ky * K;
         const int64_t off = (int64_t)(flip ? pad - ky : ky - pad) * wb + (flip ? pad - kx : kx - pad);
         const int kc = slice * KC;
         const bool second = kc >= c1;
@@ -231,7 +237,7 @@ struct KmConvGather {
 #pragma unroll
             for (int kx = 0; kx < 5; ++kx) {
                 const int y = s * i + (flip ? pad - ky : ky - pad), xx = s * j + (flip ? pad - kx : kx - pad);
-                if ((unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb) m |= 1u << (ky * 5 + kx);
+                if (ky < K && kx < K && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb) m |= 1u << (ky * K + kx);
             }
         c.mask = row < R ? m : 0u;
     }
@@ -252,21 +258,36 @@ struct KmConvTGather {
     int cps;                       // (c1 + c2) / 32
     int R;
     const float* zeros;
+    // General form (kernel K, SAME pad_before pb of the forward conv over the OUTPUT grid; K = 5: pb = 1, K = 3: pb = 0):
+    // class py holds taps ky = par + 2 sy with par = (py + pb) & 1, sy < (K - par + 1) / 2, and input row
+    // i = i' + off - sy with off = (py + pb - par) / 2.
+    int K = 5, pb = 1;
     struct Pos { rsrc_t rs; int bit; bool second; };
     struct Ctx { uint32_t v1, v2; unsigned mask; };   // v* -> input pixel (i', j')
-    __device__ int nchunks_of(int prob) const { return (2 + (prob >> 1)) * (2 + (prob & 1)) * cps; }
+    __device__ __forceinline__ void cls(int p, int& nt, int& off) const {
+        const int par = (p + pb) & 1;
+        nt = (K - par + 1) >> 1;
+        off = (p + pb - par) >> 1;
+    }
+    __device__ int nchunks_of(int prob) const {
+        int nty, ntx, oy, ox;
+        cls(prob >> 1, nty, oy); cls(prob & 1, ntx, ox);
+        return nty * ntx * cps;
+    }
     __device__ Pos pos(int prob, int chunk) const {
-        const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
+        int nty, ntx, oy, ox;
+        cls(prob >> 1, nty, oy); cls(prob & 1, ntx, ox);
         int seg, slice;
-        tap_slice(chunk, ntap, seg, slice);
+        tap_slice(chunk, nty * ntx, seg, slice);
         const int kc = slice * KC;
-        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
-        const int64_t d = (int64_t)(py - sy) * ws + (px - sx);          // pixel shift of this tap
+        const int sy = ntx == 1 ? seg : ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
+        const int64_t d = (int64_t)(oy - sy) * ws + (ox - sx);          // pixel shift of this tap
         const bool second = kc >= c1;
         return Pos{make_rsrc(second ? s2 + d * ld2 + (kc - c1) : s1 + d * ld1 + kc), sy * 3 + sx, second};
     }
     __device__ void prep(int prob, int row, int k4, Ctx& c) const {
-        const int py = prob >> 1, px = prob & 1;
+        int nty, ntx, oy, ox;
+        cls(prob >> 1, nty, oy); cls(prob & 1, ntx, ox);
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
         const int64_t pix = (int64_t)i * ws + j;
         c.v1 = (uint32_t)(((int64_t)n * hs * ws + pix) * ld1 + k4) * 4u;
@@ -276,7 +297,7 @@ struct KmConvTGather {
         for (int sy = 0; sy < 3; ++sy)
 #pragma unroll
             for (int sx = 0; sx < 3; ++sx)
-                if ((unsigned)(i + py - sy) < (unsigned)hs && (unsigned)(j + px - sx) < (unsigned)ws) m |= 1u << (sy * 3 + sx);
+                if ((unsigned)(i + oy - sy) < (unsigned)hs && (unsigned)(j + ox - sx) < (unsigned)ws) m |= 1u << (sy * 3 + sx);
         c.mask = row < R ? m : 0u;
     }
     __device__ float4 load(const Ctx& c, const Pos& q) const {
@@ -290,22 +311,24 @@ struct KmConvTWeights {
     const float* w; int ca, cb;    // cb = c1 + c2
     int cps;
     const float* zeros;
-    int flip25 = 0;                // 1: B operand of KmConvGather{flip = 1}: all 25 taps, tap index = seg itself
+    int flip25 = 0;                // 1: B operand of KmConvGather{flip = 1}: all K*K taps, tap index = seg itself
+    int K = 5, pb = 1;             // as in KmConvTGather
     struct Pos { rsrc_t rs; };
     struct Ctx { uint32_t v; };
     __device__ int nchunks_of(int) const { return 0; }
     __device__ Pos pos(int prob, int chunk) const {
         if (flip25) {              // out[y,x,c] = sum in[y+pad-ky, x+pad-kx, k] * w[ky,kx,c,k]: same (ky,kx) on both sides
             int seg, slice;
-            tap_slice(chunk, 25, seg, slice);
+            tap_slice(chunk, K * K, seg, slice);
             return Pos{make_rsrc(w + (int64_t)seg * ca * cb + slice * KC)};
         }
-        const int py = prob >> 1, px = prob & 1, ntx = 2 + px, ntap = (2 + py) * ntx;
+        const int pary = ((prob >> 1) + pb) & 1, parx = ((prob & 1) + pb) & 1;
+        const int nty = (K - pary + 1) >> 1, ntx = (K - parx + 1) >> 1;
         int seg, slice;
-        tap_slice(chunk, ntap, seg, slice);
-        const int sy = ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
-        const int ky = 1 - py + 2 * sy, kx = 1 - px + 2 * sx;
-        return Pos{make_rsrc(w + (int64_t)(ky * 5 + kx) * ca * cb + slice * KC)};
+        tap_slice(chunk, nty * ntx, seg, slice);
+        const int sy = ntx == 1 ? seg : ntx == 2 ? seg >> 1 : seg / 3, sx = seg - sy * ntx;
+        const int ky = pary + 2 * sy, kx = parx + 2 * sx;
+        return Pos{make_rsrc(w + (int64_t)(ky * K + kx) * ca * cb + slice * KC)};
     }
     __device__ void prep(int, int row, int k4, Ctx& c) const { c.v = row < ca ? (uint32_t)(row * cb + k4) * 4u : OOB; }
     __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
@@ -384,7 +407,7 @@ struct NmPlain {
     int R;           // valid r
     int K;           // valid k
     const float* zeros;
-    int seglen = 0;
+    int seglen = 0, ntap = 25;
     struct Pos { rsrc_t rs; int kleft; };
     struct Ctx { uint32_t v; int kk; };
     __device__ int nchunks_of(int) const { return (K + KC - 1) / KC; }
@@ -392,7 +415,7 @@ struct NmPlain {
         int k0 = chunk * KC;
         if (seglen) {
             int seg, slice;
-            tap_slice(chunk, 25, seg, slice);
+            tap_slice(chunk, ntap, seg, slice);
             k0 = seg * seglen + slice * KC;
         }
         return Pos{make_rsrc(p0 + (int64_t)k0 * ld0), K - chunk * KC};
@@ -458,12 +481,12 @@ struct NmWgradBig {
     PixDiv pd;
     int npix;        // imgs * hs * ws
     const float* zeros;
-    int s = 2, pad = 1;
+    int s = 2, pad = 1, K = 5;
     struct Pos { rsrc_t rs; int k0, ky, kx; };
     struct Ctx { int kk; uint32_t r; };           // r = channel byte offset or OOB
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
     __device__ Pos pos(int prob, int chunk) const {
-        const int ky = prob / 5, kx = prob - ky * 5;
+        const int ky = prob / K, kx = prob - ky * K;
         return Pos{make_rsrc(big), chunk * KC, ky, kx};
     }
     __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r = r4 < ca ? (uint32_t)r4 * 4u : OOB; }

@@ -52,18 +52,20 @@ class Translator:
     Thread-compatible, not thread-safe -- like the single tf.Session it replaces.
     """
 
-    VARIANTS = {"skipnew": _lib.CTX_VARIANT_SKIPNEW, "real": _lib.CTX_VARIANT_REAL}
+    VARIANTS = {"skipnew": _lib.CTX_VARIANT_SKIPNEW, "real": _lib.CTX_VARIANT_REAL, "inception2": _lib.CTX_VARIANT_INCEPTION2}
     PRECISIONS = {"f32": _lib.CTX_PREC_F32, "bf16x3": _lib.CTX_PREC_BF16X3}
 
     def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None,
-                 variant="skipnew", precision=None):
+                 variant="skipnew", precision=None, C=3):
         """variant "skipnew": ContextSkipNew (sampler names push/reach/strike/throw); "real": ContextAEReal
-        (names real/sweep; pass H=36, W=64, featsize=100 -- df_dim is ignored, rllab/sampler/base.py:134-137)."""
+        (names real/sweep; pass H=36, W=64, featsize=100 -- df_dim is ignored, rllab/sampler/base.py:134-137);
+        "inception2": ContextAEInception2 on Mixed_7c feature maps (mode 'oursinception'; pass the feature grid as H, W
+        and C=2048; float inputs only: translate_f32 / encode_f32 / train_step / evaluate)."""
         precision = precision or os.environ.get("CTX_PRECISION", "f32")     # "f32" (exact) | "bf16x3" (split-bf16 products)
         self._lib = _lib.load()
         self.variant, self.precision = variant, precision
-        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, 3, df_dim, featsize, max_batch, self.PRECISIONS[precision])
-        self.H, self.W, self.df_dim, self.featsize, self.max_batch = H, W, df_dim, featsize, max_batch
+        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, C, df_dim, featsize, max_batch, self.PRECISIONS[precision])
+        self.H, self.W, self.C, self.df_dim, self.featsize, self.max_batch = H, W, C, df_dim, featsize, max_batch
         self.device = device
         self._h = ctypes.c_void_p()
         rc = self._lib.ctx_create_ex(ctypes.byref(self.cfg), device, ctypes.c_void_p(stream or 0),
@@ -96,13 +98,13 @@ class Translator:
         _lib.check(self._lib, self._h, rc)
 
     @staticmethod
-    def param_total(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew"):
-        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, 3, df_dim, featsize, 1, 0)
+    def param_total(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3):
+        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, C, df_dim, featsize, 1, 0)
         return int(_lib.load().ctx_param_total_for(ctypes.byref(cfg)))
 
     @staticmethod
-    def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew"):
-        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, 3, df_dim, featsize, 1, 0)
+    def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3):
+        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, C, df_dim, featsize, 1, 0)
         return int(_lib.load().ctx_arena_bytes(ctypes.byref(cfg))) // 4
 
     # ------------------------------------------------------------------ parameters (tf.train.Saver)
@@ -200,6 +202,27 @@ class Translator:
         self._ck(self._lib.ctx_translate(self._h, _up(src), _up(ctx0), int(batched), B, _fp(pred), _fp(feat)))
         return pred, feat
 
+    def translate_f32(self, src, ctx0):
+        """translate() on float inputs [B,H,W,C]: frames in [-1,1] or, for variant "inception2", feature maps."""
+        src = _f32(src)
+        B = src.shape[0]
+        src = _f32(src, (B, self.H, self.W, self.C))
+        ctx0 = _f32(ctx0)
+        batched = ctx0.ndim == 4
+        ctx0 = _f32(ctx0, (B, self.H, self.W, self.C) if batched else (self.H, self.W, self.C))
+        pred = np.empty(src.shape, np.float32)
+        feat = np.empty((B, self.featsize), np.float32)
+        self._ck(self._lib.ctx_translate_f32(self._h, _fp(src), _fp(ctx0), int(batched), B, _fp(pred), _fp(feat)))
+        return pred, feat
+
+    def encode_f32(self, frames):
+        """input_z of float inputs [B,H,W,C] (the `conv` encoder)."""
+        fr = _f32(frames)
+        fr = _f32(fr, (fr.shape[0], self.H, self.W, self.C))
+        feat = np.empty((fr.shape[0], self.featsize), np.float32)
+        self._ck(self._lib.ctx_encode_f32(self._h, _fp(fr), fr.shape[0], _fp(feat)))
+        return feat
+
     def encode(self, frames, return_frames=True):
         """frames uint8 [B,H,W,3] -> (input_z f32 [B,featsize], image_trans[0] f32 [B,H,W,3])."""
         fr = _u8(frames)
@@ -214,7 +237,7 @@ class Translator:
     # ------------------------------------------------------------------ training
     def _triple(self, src, ctx, tgt):
         src = _f32(src)
-        shp = (src.shape[0], self.H, self.W, 3)
+        shp = (src.shape[0], self.H, self.W, self.C)
         return _f32(src, shp), _f32(ctx, shp), _f32(tgt, shp), shp[0]
 
     def train_step(self, src, ctx, tgt, lr=1e-4):

@@ -51,6 +51,11 @@ enum {
 
 enum {
     CTX_VARIANT_SKIPNEW = 0, /* ContextSkipNew, gym/envs/mujoco/arm_shaping.py:1260-1354 */
+    CTX_VARIANT_INCEPTION2 = 2, /* ContextAEInception2, arm_shaping.py:1786-1894 (mode 'oursinception'), built as
+                                   strides [1,2,1,2], kernels [3,3,3,3], filters [16d,16d,8d,8d] (d = df_dim = 64:
+                                   rllab/sampler/base.py:126).  Inputs are Inception-v3 Mixed_7c FEATURE MAPS, f32
+                                   [B, H, W, C] with C a multiple of 32 (2048; H = W = 2 for 125x125 frames, 8 for
+                                   299x299); out = decode + tgtctx.  The uint8 entry points are refused: use *_f32. */
     CTX_VARIANT_REAL = 1     /* ContextAEReal, arm_shaping.py:1599-1684 (sampler names 'real', 'sweep'): shared
                                 encoder, filters 32/16/16/8, strides 1/2/1/2; H, W multiples of 4, featsize (100)
                                 a multiple of 4, df_dim ignored, keep_prob = 1 */
@@ -117,6 +122,11 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
 /* frames [B,H,W,3] uint8 -> feat [B,featsize] = model.input_z; frames_f32 (nullable) [B,H,W,3] =
  * image_trans[0] = (x/255 - 0.5)*2. */
 int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32);
+/* The same two fetches on float inputs [B,H,W,C]: frames already scaled to [-1,1], or -- for
+ * CTX_VARIANT_INCEPTION2, where image_trans IS the feature tensor (base.py:127-132) -- Mixed_7c feature maps. */
+int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ctx_batched, int B,
+                      float* pred, float* feat);
+int ctx_encode_f32(ctx_handle* h, const float* frames, int B, float* feat);
 
 /* ---- training --------------------------------------------------------------------------------- */
 /* src/ctx/tgt [B,H,W,3] f32 in [-1,1] (tfinput[0], [1], [2]).  scalars = {loss, simloss, recon1,

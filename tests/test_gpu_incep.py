@@ -1,0 +1,91 @@
+"""ContextAEInception2 (CTX_VARIANT_INCEPTION2) through the C ABI against oracle/ctx_oracle_incep.py, on synthetic
+feature maps (the Inception-v3 front end that would produce them is not built; its weights are absent from the
+reference tree anyway -- SURVEY.md 8a row a8)."""
+import numpy as np
+import pytest
+
+from oracle import ctx_oracle_incep as oi
+
+pytestmark = pytest.mark.gpu
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import Translator
+    return Translator
+
+
+def make(H, W, C, d, F, B, seed=0, stddev=0.05):
+    cfg = oi.Incep2Config(H=H, W=W, C=C, featsize=F, filters=(16 * d, 16 * d, 8 * d, 8 * d))
+    p = oi.init_params(cfg, 60 + seed, np.float64, stddev=stddev)
+    brng = np.random.default_rng(seed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    rng = np.random.default_rng(seed)
+    # Mixed_7c activations are post-ReLU: non-negative, sparse-ish
+    feats = [np.maximum(rng.standard_normal((B, H, W, C)), 0).astype(np.float32) for _ in range(3)]
+    return cfg, p, feats
+
+
+def test_param_inventory(T):
+    cfg = oi.Incep2Config(H=2, W=2, C=64, featsize=64, filters=(64, 64, 32, 32))
+    with T(2, 2, df_dim=4, featsize=64, max_batch=1, variant="inception2", C=64) as tr:
+        info = tr.param_info()
+        assert tr.n_params == oi.param_count(cfg)
+    assert [(n, s) for n, s, _ in info] == [(n, tuple(s)) for n, s in oi.param_specs(cfg)]
+    # the production shape (base.py:126): 2048-channel maps, filters 1024/1024/512/512
+    from imitation_from_observation_amd import Translator
+    assert Translator.param_total(2, 2, 64, 1024, variant="inception2", C=2048) == oi.param_count(oi.Incep2Config())
+
+
+@pytest.mark.parametrize("H,W,C,d,F,B", [(2, 2, 64, 4, 64, 3), (8, 8, 32, 4, 32, 2), (4, 4, 96, 4, 64, 5), (4, 8, 64, 4, 32, 2)])
+def test_incep2_forward_backward_matches_oracle(T, H, W, C, d, F, B):
+    cfg, p, (src, ctx, tgt) = make(H, W, C, d, F, B)
+    res, c = oi.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = oi.backward(p, c, cfg)
+    with T(H, W, df_dim=d, featsize=F, max_batch=B, variant="inception2", C=C) as tr:
+        tr.set_params(p)
+        np.testing.assert_array_equal(tr.get_params_flat(), oi.flatten(p, cfg, np.float32))
+        ev = tr.evaluate(src, ctx, tgt)
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(ev[k] - res[k]) <= 1e-5 * abs(res[k]) + 1e-6, k
+        assert relmax(ev["out"], res["out"]) < 1e-5 and relmax(ev["out2"], res["out2"]) < 1e-5
+        sc = tr.train_step(src, ctx, tgt, lr=0.0)
+        assert abs(sc["loss"] - res["loss"]) <= 1e-5 * abs(res["loss"])
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-4, n
+        # the reward hook's two fetches on feature maps (base.py:216-218, 234-235 with image_trans = features)
+        pred, feat = tr.translate_f32(src, ctx[0])
+        opred, ofeat = oi.translate(p, src.astype(np.float64), ctx[0].astype(np.float64), cfg)
+        assert relmax(pred, opred) < 1e-5 and relmax(feat, ofeat) < 1e-5
+        assert relmax(tr.encode_f32(tgt), oi.encode(p, tgt.astype(np.float64), cfg)) < 1e-5
+        # uint8 frames are refused with a message, not mis-read
+        from imitation_from_observation_amd import CtxError
+        with pytest.raises(CtxError, match="Inception"):
+            tr.translate(np.zeros((B, H, W, 3), np.uint8), np.zeros((H, W, 3), np.uint8))
+
+
+def test_incep2_adam_and_split_precision(T):
+    H, W, C, d, F, B = 2, 2, 128, 8, 128, 4
+    cfg, p, (src, ctx, tgt) = make(H, W, C, d, F, B, seed=2)
+    res, _ = oi.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    with T(H, W, df_dim=d, featsize=F, max_batch=B, variant="inception2", C=C) as a, \
+         T(H, W, df_dim=d, featsize=F, max_batch=B, variant="inception2", C=C, precision="bf16x3") as b:
+        a.set_params(p)
+        b.set_params(p)
+        l0 = a.train_step(src, ctx, tgt, lr=1e-4)["loss"]
+        for _ in range(3):
+            l1 = a.train_step(src, ctx, tgt, lr=1e-4)["loss"]
+        assert abs(l0 - res["loss"]) <= 1e-5 * res["loss"] and l1 < l0
+        evb = b.evaluate(src, ctx, tgt)
+        assert relmax(evb["out"], res["out"]) < 2e-4 and abs(evb["loss"] - res["loss"]) <= 2e-4 * res["loss"]
