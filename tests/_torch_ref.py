@@ -171,3 +171,65 @@ def forward_incep2(p, src, ctx, tgt, H, W, strides, filters):
     sim = ((trans_z - tgt_z) ** 2).mean() * 1e3
     r1, r2 = 0.5 * ((tgt - out) ** 2).sum(), 0.5 * ((tgt - out2) ** 2).sum()
     return dict(input_z=src_z, translated_z=trans_z, out=out, out2=out2, simloss=sim, recon1=r1, recon2=r2, loss=r1 + r2 + sim)
+
+
+def inception_v3_mixed7c(p, x_nhwc):
+    """nets/inception_v3.py:93-416 through torch ops (conv2d with explicit TF padding, batch_norm in eval mode without
+    scale, relu, max/avg pooling with TF's SAME semantics); shares no code with oracle/inception_oracle.py."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    S = "InceptionV3/"
+
+    def conv(x, scope, stride=1, padding="SAME"):
+        w = p[scope + "/weights"]
+        kh, kw = w.shape[0], w.shape[1]
+        if padding == "SAME":
+            _, pt, pb = tf_same(x.shape[2], kh, stride)
+            _, pl, pr = tf_same(x.shape[3], kw, stride)
+            x = F.pad(x, (pl, pr, pt, pb))
+        y = F.conv2d(x, w.permute(3, 2, 0, 1), None, stride=stride)
+        y = F.batch_norm(y, p[scope + "/BatchNorm/moving_mean"], p[scope + "/BatchNorm/moving_variance"], None,
+                         p[scope + "/BatchNorm/beta"], training=False, eps=0.001)
+        return F.relu(y)
+
+    mp = lambda t: F.max_pool2d(t, 3, 2)
+    ap = lambda t: F.avg_pool2d(t, 3, 1, padding=1, count_include_pad=False)
+    x = conv(x, S + "Conv2d_1a_3x3", 2, "VALID")
+    x = conv(x, S + "Conv2d_2a_3x3", 1, "VALID")
+    x = conv(x, S + "Conv2d_2b_3x3")
+    x = mp(x)
+    x = conv(x, S + "Conv2d_3b_1x1", 1, "VALID")
+    x = conv(x, S + "Conv2d_4a_3x3", 1, "VALID")
+    x = mp(x)
+    for name, b1 in (("Mixed_5b", ("Conv2d_0a_1x1", "Conv2d_0b_5x5")), ("Mixed_5c", ("Conv2d_0b_1x1", "Conv_1_0c_5x5")),
+                     ("Mixed_5d", ("Conv2d_0a_1x1", "Conv2d_0b_5x5"))):
+        P = S + name + "/"
+        x = torch.cat([conv(x, P + "Branch_0/Conv2d_0a_1x1"),
+                       conv(conv(x, P + "Branch_1/" + b1[0]), P + "Branch_1/" + b1[1]),
+                       conv(conv(conv(x, P + "Branch_2/Conv2d_0a_1x1"), P + "Branch_2/Conv2d_0b_3x3"), P + "Branch_2/Conv2d_0c_3x3"),
+                       conv(ap(x), P + "Branch_3/Conv2d_0b_1x1")], 1)
+    P = S + "Mixed_6a/"
+    x = torch.cat([conv(x, P + "Branch_0/Conv2d_1a_1x1", 2, "VALID"),
+                   conv(conv(conv(x, P + "Branch_1/Conv2d_0a_1x1"), P + "Branch_1/Conv2d_0b_3x3"), P + "Branch_1/Conv2d_1a_1x1", 2, "VALID"),
+                   mp(x)], 1)
+    for name in ("Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e"):
+        P = S + name + "/"
+        t = conv(conv(conv(x, P + "Branch_1/Conv2d_0a_1x1"), P + "Branch_1/Conv2d_0b_1x7"), P + "Branch_1/Conv2d_0c_7x1")
+        u = x
+        for sc in ("Conv2d_0a_1x1", "Conv2d_0b_7x1", "Conv2d_0c_1x7", "Conv2d_0d_7x1", "Conv2d_0e_1x7"):
+            u = conv(u, P + "Branch_2/" + sc)
+        x = torch.cat([conv(x, P + "Branch_0/Conv2d_0a_1x1"), t, u, conv(ap(x), P + "Branch_3/Conv2d_0b_1x1")], 1)
+    P = S + "Mixed_7a/"
+    t = x
+    for sc in ("Conv2d_0a_1x1", "Conv2d_0b_1x7", "Conv2d_0c_7x1"):
+        t = conv(t, P + "Branch_1/" + sc)
+    x = torch.cat([conv(conv(x, P + "Branch_0/Conv2d_0a_1x1"), P + "Branch_0/Conv2d_1a_3x3", 2, "VALID"),
+                   conv(t, P + "Branch_1/Conv2d_1a_3x3", 2, "VALID"), mp(x)], 1)
+    for name, b1b in (("Mixed_7b", "Conv2d_0b_3x1"), ("Mixed_7c", "Conv2d_0c_3x1")):
+        P = S + name + "/"
+        t = conv(x, P + "Branch_1/Conv2d_0a_1x1")
+        u = conv(conv(x, P + "Branch_2/Conv2d_0a_1x1"), P + "Branch_2/Conv2d_0b_3x3")
+        x = torch.cat([conv(x, P + "Branch_0/Conv2d_0a_1x1"),
+                       conv(t, P + "Branch_1/Conv2d_0b_1x3"), conv(t, P + "Branch_1/" + b1b),
+                       conv(u, P + "Branch_2/Conv2d_0c_1x3"), conv(u, P + "Branch_2/Conv2d_0d_3x1"),
+                       conv(ap(x), P + "Branch_3/Conv2d_0b_1x1")], 1)
+    return x.permute(0, 2, 3, 1)
