@@ -36,6 +36,17 @@ _U8 = _c.POINTER(_c.c_uint8)
 _CFG = _c.POINTER(CtxConfig)
 
 # name -> (restype, argtypes): every symbol include/ctxtrans.h declares
+class CnnBuf(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("h", "w", "c")]
+
+
+class CnnOp(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("kind", "src", "dst", "dst_ch0", "kh", "kw", "stride", "same", "cout", "reserved")] + \
+               [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
+
+
+CTX_CNN_CONV, CTX_CNN_MAXPOOL, CTX_CNN_AVGPOOL = 0, 1, 2
+
 SIGNATURES = {
     "ctx_abi_version": (_c.c_int, []),
     "ctx_create": (_c.c_int, [_CFG, _c.c_int, _c.POINTER(_P)]),
@@ -76,6 +87,16 @@ SIGNATURES = {
     "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
                                     _c.POINTER(_c.c_int)]),
     "ctx_debug_read": (_c.c_int, [_P, _c.c_char_p, _F, _c.c_size_t]),
+    "ctx_cnn_create": (_c.c_int, [_c.POINTER(CnnBuf), _c.c_int, _c.POINTER(CnnOp), _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _P,
+                                  _c.POINTER(_P)]),
+    "ctx_cnn_destroy": (None, [_P]),
+    "ctx_cnn_last_error": (_c.c_char_p, [_P]),
+    "ctx_cnn_set_weights": (_c.c_int, [_P, _F, _c.c_size_t]),
+    "ctx_cnn_forward_u8": (_c.c_int, [_P, _U8, _c.c_int, _F]),
+    "ctx_cnn_forward_dev": (_c.c_int, [_P, _P, _c.c_int, _c.POINTER(_P)]),
+    "ctx_cnn_read_buffer": (_c.c_int, [_P, _c.c_int, _c.c_int, _F]),
+    "ctx_cnn_stream": (_P, [_P]),
+    "ctx_cnn_sync": (_c.c_int, [_P]),
 }
 
 _lib = None

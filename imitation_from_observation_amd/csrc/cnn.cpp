@@ -1,0 +1,235 @@
+// cnn.cpp -- forward executor for a frozen conv net given as an op list: the Inception-v3 front end of mode
+// 'oursinception' (nets/inception_v3.py:93-416 under nets/inception_utils.py:31-71, is_training=False), C ABI
+// ctx_cnn_* in include/ctxtrans.h.  The GRAPH lives on the host side (imitation_from_observation_amd/
+// inception_frontend.py mirrors the reference's Python graph builder); this file only executes it:
+//   conv     slim.conv2d = conv + batch norm (moving statistics) + ReLU.  The host folds the batch norm into the
+//            filter and a bias; the conv is the same implicit GEMM as the translator's (KmConvGather with a KH x KW
+//            kernel, stride, SAME/VALID padding x NmPlain filter rows), epilogue bias + ReLU, written into a CHANNEL
+//            SLICE of the destination tensor -- tf.concat never copies.
+//   maxpool  3x3 stride 2 VALID;  avgpool  3x3 stride 1 SAME (mean over the taps inside the image).
+// Activations are NHWC with the channel count rounded up to 32 (the 3-channel frames, the 80- and 48-wide tensors);
+// padded channels are zero because nothing ever writes them and the matching filter rows are zero.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/ctxtrans.h"
+#include "launch.h"
+
+using namespace ctx;
+
+struct ctx_cnn {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int max_images = 0, precision = 0;
+    std::vector<ctx_cnn_buf> bufs;
+    std::vector<ctx_cnn_op> ops;
+    std::vector<float*> dbuf;
+    float* weights = nullptr;
+    int64_t weight_floats = 0;
+    uint8_t* u8 = nullptr;
+    float* f32in = nullptr;
+    float* slab = nullptr;
+    int64_t slab_floats = 0;
+    float* zeros = nullptr;
+    std::string err;
+};
+
+namespace {
+thread_local std::string g_cnn_create_error;
+
+int cfail(ctx_cnn* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_cnn_create_error = buf;
+    return code;
+}
+#define CNN_HIP(h, expr)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return cfail(h, CTX_E_DEVICE, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+void out_dims(const ctx_cnn_buf& in, const ctx_cnn_op& op, int& ho, int& wo) {
+    if (op.same) { ho = (in.h + op.stride - 1) / op.stride; wo = (in.w + op.stride - 1) / op.stride; }
+    else { ho = (in.h - op.kh) / op.stride + 1; wo = (in.w - op.kw) / op.stride + 1; }
+}
+int same_before(int n, int k, int s) {
+    const int out = (n + s - 1) / s, total = (out - 1) * s + k - n;
+    return total > 0 ? total / 2 : 0;
+}
+
+int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>& ops, int64_t weight_floats, int max_images) {
+    if (bufs.empty() || ops.empty()) return cfail(nullptr, CTX_E_INVALID, "empty graph");
+    for (size_t i = 0; i < bufs.size(); ++i) {
+        const ctx_cnn_buf& b = bufs[i];
+        if (b.h <= 0 || b.w <= 0 || b.c <= 0 || b.c % 32) return cfail(nullptr, CTX_E_INVALID, "buffer %zu: %dx%dx%d (channels must be a positive multiple of 32)", i, b.h, b.w, b.c);
+        if ((int64_t)max_images * b.h * b.w * b.c * 4 >= (1ll << 31))
+            return cfail(nullptr, CTX_E_INVALID, "buffer %zu needs >= 2 GiB at max_images %d: lower max_images (forward() chunks the batch)", i, max_images);
+    }
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const ctx_cnn_op& op = ops[i];
+        if (op.src < 0 || op.dst < 0 || op.src >= (int)bufs.size() || op.dst >= (int)bufs.size() || op.src == op.dst)
+            return cfail(nullptr, CTX_E_INVALID, "op %zu: bad buffer ids", i);
+        const ctx_cnn_buf &in = bufs[op.src], &out = bufs[op.dst];
+        int ho, wo;
+        ctx_cnn_op o = op;
+        if (op.kind != CTX_CNN_CONV) { o.kh = o.kw = 3; o.stride = op.kind == CTX_CNN_MAXPOOL ? 2 : 1; o.same = op.kind == CTX_CNN_AVGPOOL; }
+        out_dims(in, o, ho, wo);
+        if (ho != out.h || wo != out.w) return cfail(nullptr, CTX_E_INVALID, "op %zu: output grid %dx%d but buffer %d is %dx%d", i, ho, wo, op.dst, out.h, out.w);
+        const int cw = op.kind == CTX_CNN_CONV ? op.cout : in.c;
+        if (op.dst_ch0 < 0 || op.dst_ch0 % 4 || op.dst_ch0 + cw > out.c) return cfail(nullptr, CTX_E_INVALID, "op %zu: channel slice [%d,%d) outside buffer %d", i, op.dst_ch0, op.dst_ch0 + cw, op.dst);
+        if (op.kind == CTX_CNN_CONV) {
+            if (op.kh < 1 || op.kw < 1 || op.kh * op.kw > 25 || op.cout <= 0 || op.cout % 4 || (op.stride != 1 && op.stride != 2))
+                return cfail(nullptr, CTX_E_INVALID, "op %zu: unsupported conv %dx%d stride %d cout %d", i, op.kh, op.kw, op.stride, op.cout);
+            const int64_t nw = (int64_t)op.kh * op.kw * in.c * op.cout;
+            if (op.w_off < 0 || op.w_off % 4 || op.w_off + nw > weight_floats || op.b_off < 0 || op.b_off + op.cout > weight_floats)
+                return cfail(nullptr, CTX_E_INVALID, "op %zu: weights outside the blob", i);
+        } else if (op.kind != CTX_CNN_MAXPOOL && op.kind != CTX_CNN_AVGPOOL) return cfail(nullptr, CTX_E_INVALID, "op %zu: unknown kind %d", i, op.kind);
+    }
+    return CTX_OK;
+}
+
+int run(ctx_cnn* h, int n) {
+    const SplitWs ws{h->slab, h->slab_floats, h->precision};
+    for (const ctx_cnn_op& op : h->ops) {
+        const ctx_cnn_buf &in = h->bufs[op.src], &out = h->bufs[op.dst];
+        const float* x = h->dbuf[op.src];
+        float* y = h->dbuf[op.dst] + op.dst_ch0;
+        if (op.kind == CTX_CNN_MAXPOOL) { maxpool3x3s2(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
+        if (op.kind == CTX_CNN_AVGPOOL) { avgpool3x3s1(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
+        const int R = n * out.h * out.w;
+        KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
+        a.s = op.stride; a.K = op.kh; a.KW = op.kw;
+        a.pad = op.same ? same_before(in.h, op.kh, op.stride) : 0;
+        a.padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
+        const float* w = h->weights + op.w_off;
+        NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
+        Epi ep;
+        ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
+        conv_fwd(h->stream, a, b, ep, R, op.cout, ws);
+    }
+    if (hipGetLastError() != hipSuccess) return cfail(h, CTX_E_DEVICE, "kernel launch failed");
+    return CTX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, int nops, int64_t weight_floats, int max_images,
+                   int precision, int device, void* stream, ctx_cnn** out) {
+    if (!out) return cfail(nullptr, CTX_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!bufs || !ops || nbufs <= 0 || nops <= 0 || weight_floats <= 0 || max_images <= 0) return cfail(nullptr, CTX_E_INVALID, "bad arguments");
+    if (precision != CTX_PREC_F32 && precision != CTX_PREC_BF16X3) return cfail(nullptr, CTX_E_INVALID, "unsupported precision %d", precision);
+    std::vector<ctx_cnn_buf> vb(bufs, bufs + nbufs);
+    std::vector<ctx_cnn_op> vo(ops, ops + nops);
+    if (validate(vb, vo, weight_floats, max_images) != CTX_OK) return CTX_E_INVALID;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return cfail(nullptr, CTX_E_DEVICE, "no HIP device available; libctxtrans has no CPU path");
+    if (device < 0 || device >= ndev) return cfail(nullptr, CTX_E_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, CTX_E_DEVICE, "hipSetDevice failed");
+    ctx_cnn* h = new ctx_cnn();
+    h->device = device; h->max_images = max_images; h->precision = precision; h->bufs = vb; h->ops = vo; h->weight_floats = weight_floats;
+    bool ok = true;
+    if (stream) h->stream = (hipStream_t)stream;
+    else { ok = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess; h->own_stream = ok; }
+    auto alloc = [&](void** p, size_t bytes, bool zero) {
+        if (!ok) return;
+        ok = hipMalloc(p, bytes) == hipSuccess && (!zero || hipMemset(*p, 0, bytes) == hipSuccess);
+    };
+    h->dbuf.assign(nbufs, nullptr);
+    for (int i = 0; i < nbufs; ++i) alloc((void**)&h->dbuf[i], (size_t)max_images * vb[i].h * vb[i].w * vb[i].c * sizeof(float), true);
+    alloc((void**)&h->weights, (size_t)weight_floats * sizeof(float), true);
+    const size_t npix = (size_t)max_images * vb[0].h * vb[0].w;
+    alloc((void**)&h->u8, npix * 3, false);
+    alloc((void**)&h->f32in, npix * 3 * sizeof(float), false);
+    h->slab_floats = 32ll << 20;
+    alloc((void**)&h->slab, (size_t)h->slab_floats * sizeof(float), false);
+    alloc((void**)&h->zeros, 256, true);
+    if (!ok) { cfail(nullptr, CTX_E_NOMEM, "device allocation failed"); ctx_cnn_destroy(h); return CTX_E_NOMEM; }
+    *out = h;
+    return CTX_OK;
+}
+
+void ctx_cnn_destroy(ctx_cnn* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (float* p : h->dbuf) if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->weights, (void*)h->u8, (void*)h->f32in, (void*)h->slab, (void*)h->zeros}) if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* ctx_cnn_last_error(const ctx_cnn* h) { return h ? h->err.c_str() : g_cnn_create_error.c_str(); }
+
+int ctx_cnn_set_weights(ctx_cnn* h, const float* blob, size_t n) {
+    if (!h || !blob) return CTX_E_INVALID;
+    if ((int64_t)n != h->weight_floats) return cfail(h, CTX_E_INVALID, "expected %lld floats, got %zu", (long long)h->weight_floats, n);
+    CNN_HIP(h, hipSetDevice(h->device));
+    CNN_HIP(h, hipMemcpyAsync(h->weights, blob, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    CNN_HIP(h, hipStreamSynchronize(h->stream));
+    return CTX_OK;
+}
+
+// frames: host uint8 [n, H, W, 3] (preprocessed like base.py:116-119) -> out: host f32 [n, h, w, c] of the LAST buffer
+int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out) {
+    if (!h || !frames || n <= 0) return h ? cfail(h, CTX_E_INVALID, "bad arguments") : CTX_E_INVALID;
+    CNN_HIP(h, hipSetDevice(h->device));
+    const ctx_cnn_buf &b0 = h->bufs.front(), &bl = h->bufs.back();
+    const int64_t pix_in = (int64_t)b0.h * b0.w, per_out = (int64_t)bl.h * bl.w * bl.c;
+    for (int i0 = 0; i0 < n; i0 += h->max_images) {
+        const int m = n - i0 < h->max_images ? n - i0 : h->max_images;
+        CNN_HIP(h, hipMemcpyAsync(h->u8, frames + (int64_t)i0 * pix_in * 3, (size_t)m * pix_in * 3, hipMemcpyHostToDevice, h->stream));
+        pad_channels_u8(h->stream, h->u8, h->dbuf[0], m * pix_in, b0.c);
+        const int rc = run(h, m);
+        if (rc != CTX_OK) return rc;
+        if (out) CNN_HIP(h, hipMemcpyAsync(out + (int64_t)i0 * per_out, h->dbuf.back(), (size_t)m * per_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        CNN_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return CTX_OK;
+}
+
+// d_frames: DEVICE f32 [n, H, W, 3] in [-1,1], n <= max_images; *d_out: device pointer of the last buffer [n, h, w, c].
+// Asynchronous on the handle's stream.
+int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** d_out) {
+    if (!h || !d_frames || n <= 0 || n > h->max_images) return h ? cfail(h, CTX_E_INVALID, "n must be in [1, max_images]") : CTX_E_INVALID;
+    CNN_HIP(h, hipSetDevice(h->device));
+    const ctx_cnn_buf& b0 = h->bufs.front();
+    pad_channels_f32(h->stream, d_frames, h->dbuf[0], (int64_t)n * b0.h * b0.w, b0.c);
+    const int rc = run(h, n);
+    if (rc != CTX_OK) return rc;
+    if (d_out) *d_out = h->dbuf.back();
+    return CTX_OK;
+}
+
+// copies buffer `index` (n images) to the host: bring-up and the end-point tests
+int ctx_cnn_read_buffer(ctx_cnn* h, int index, int n, float* out) {
+    if (!h || !out || index < 0 || index >= (int)h->bufs.size() || n <= 0 || n > h->max_images) return CTX_E_INVALID;
+    const ctx_cnn_buf& b = h->bufs[index];
+    CNN_HIP(h, hipSetDevice(h->device));
+    CNN_HIP(h, hipMemcpyAsync(out, h->dbuf[index], (size_t)n * b.h * b.w * b.c * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    CNN_HIP(h, hipStreamSynchronize(h->stream));
+    return CTX_OK;
+}
+
+void* ctx_cnn_stream(ctx_cnn* h) { return h ? (void*)h->stream : nullptr; }
+int ctx_cnn_sync(ctx_cnn* h) {
+    if (!h) return CTX_E_INVALID;
+    CNN_HIP(h, hipSetDevice(h->device));
+    CNN_HIP(h, hipStreamSynchronize(h->stream));
+    return CTX_OK;
+}
+
+}  // extern "C"

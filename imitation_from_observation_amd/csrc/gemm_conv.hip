@@ -5,8 +5,8 @@ namespace ctx {
 void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, int M, int N, SplitWs ws) {
     NmPlain b = b_;
     b.seglen = a.tap_outer ? 0 : a.cps * KC;     // filter rows in KmConvGather's K order (A/B measured: no difference)
-    b.ntap = a.K * a.K;
-    launch_igemm<KmConvGather, NmPlain, true>(s, a, b, ep, M, N, 1, a.K * a.K * a.cps, ws);
+    b.ntap = a.ntaps();
+    launch_igemm<KmConvGather, NmPlain, true>(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     ep.rowmode = 1; ep.hs = a.hs; ep.ws = a.ws;
@@ -21,7 +21,7 @@ void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, floa
     launch_igemm(s, a, b, ep, M, 75, 1, 0, ws);
 }
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
-    launch_igemm(s, a, b, ep, M, N, 1, a.K * a.K * a.cps, ws);
+    launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, 3, ws);

@@ -107,7 +107,7 @@ struct Epi {
     int64_t lda2 = 0;
     const float* mask = nullptr;    // saved lrelu OUTPUT; v *= (mask >= 0 ? 1 : 0.2) for n < nsplit
     int64_t ldm = 0;
-    int lrelu = 0;                  // v = max(v, 0.2 v) after bias/adds
+    int lrelu = 0;                  // 1: v = max(v, 0.2 v) after bias/adds; 2: plain ReLU (the Inception front end)
     int rowmode = 0;                // 0: pix = m; 1: transposed-conv parity class; 2: (ky,e) rows of a C=3 filter
     int hs = 0, ws = 0;             // rowmode 1: small-grid size
     int64_t prob_stride = 0;        // out1 += prob * prob_stride (filter gradient: one tap per problem)
@@ -133,7 +133,7 @@ __device__ __forceinline__ void epi_store(const Epi& e, int prob, int64_t pix, i
     if (e.bias) v += e.bias[n];
     if (e.add1) v += e.add1[((e.add1_mod && pix >= e.add1_mod) ? pix - e.add1_mod : pix) * e.lda1 + n];
     if (e.add2) v += e.add2[pix * e.lda2 + n];
-    if (e.lrelu) v = fmaxf(v, LEAK * v);
+    if (e.lrelu) v = fmaxf(v, (e.lrelu == 2 ? 0.f : LEAK) * v);
     if (n < e.nsplit) {
         if (e.mask) v *= (e.mask[pix * e.ldm + n] >= 0.f) ? 1.f : LEAK;
         e.out1[(int64_t)prob * e.prob_stride + pix * e.ld1 + n] = v;
@@ -212,16 +212,21 @@ struct KmConvGather {
     int tap_outer = 0;             // K order: 0 = channel slice outer / taps inner, 1 = taps outer
     int s = 2, pad = 1, flip = 0;
     const float* x2 = nullptr; int64_t ldx2 = 0; int c1 = 1 << 30; int nmod2 = 1;
-    int K = 5;                     // kernel size (5: ContextSkipNew / ContextAEReal, 3: ContextAEInception2)
+    int K = 5;                     // kernel height (5: ContextSkipNew / ContextAEReal, 3: ContextAEInception2)
+    int KW = 0, padx = -1;         // kernel width / left pad when they differ from K / pad (1x7, 7x1, 1x3, 3x1 of Inception-v3); K*KW <= 25
+    __host__ __device__ int kw() const { return KW ? KW : K; }
+    __host__ __device__ int px() const { return padx >= 0 ? padx : pad; }
+    __host__ __device__ int ntaps() const { return K * kw(); }
     struct Pos { rsrc_t rs; int seg; bool second; };
     struct Ctx { uint32_t v, v2; unsigned mask; };   // v -> input pixel (s*i, s*j); mask bit = tap valid
-    __device__ int nchunks_of(int) const { return K * K * cps; }
+    __device__ int nchunks_of(int) const { return ntaps() * cps; }
     __device__ Pos pos(int, int chunk) const {
         int seg, slice;
         if (tap_outer) { seg = chunk / cps; slice = chunk - seg * cps; }
-        else tap_slice(chunk, K * K, seg, slice);
-        const int ky = K == 5 ? seg / 5 : seg / K, kx = seg - ky * K;
-        const int64_t off = (int64_t)(flip ? pad - ky : ky - pad) * wb + (flip ? pad - kx : kx - pad);
+        else tap_slice(chunk, ntaps(), seg, slice);
+        const int kwd = kw(), padl = px();
+        const int ky = kwd == 5 ? seg / 5 : seg / kwd, kx = seg - ky * kwd;
+        const int64_t off = (int64_t)(flip ? pad - ky : ky - pad) * wb + (flip ? padl - kx : kx - padl);
         const int kc = slice * KC;
         const bool second = kc >= c1;
         return Pos{make_rsrc(second ? x2 + off * ldx2 + (kc - c1) : x + off * ldx + kc), seg, second};
@@ -232,12 +237,11 @@ struct KmConvGather {
         c.v = (uint32_t)(((int64_t)n * hb * wb + pix) * ldx + k4) * 4u;
         c.v2 = (uint32_t)(((int64_t)(n % nmod2) * hb * wb + pix) * ldx2 + k4) * 4u;
         unsigned m = 0;
-#pragma unroll
-        for (int ky = 0; ky < 5; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 5; ++kx) {
-                const int y = s * i + (flip ? pad - ky : ky - pad), xx = s * j + (flip ? pad - kx : kx - pad);
-                if (ky < K && kx < K && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb) m |= 1u << (ky * K + kx);
+        const int kwd = kw(), padl = px();
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < kwd; ++kx) {
+                const int y = s * i + (flip ? pad - ky : ky - pad), xx = s * j + (flip ? padl - kx : kx - padl);
+                if ((unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb) m |= 1u << (ky * kwd + kx);
             }
         c.mask = row < R ? m : 0u;
     }

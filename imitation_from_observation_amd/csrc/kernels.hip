@@ -118,9 +118,73 @@ __global__ __launch_bounds__(NTHREADS) void u8_to_f32_kernel(const uint8_t* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inception-v3 front end (nets/inception_v3.py): HBM-bound helpers around the implicit-GEMM convs.
+// ------------------------------------------------------------------------------------------------
+// frames [npix][3] (uint8 or f32 in [-1,1]) -> [npix][cpad] with channels 3.. left untouched (the buffer is zeroed once)
+template <class T>
+__global__ __launch_bounds__(NTHREADS) void pad_channels_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t npix, int cpad) {
+    for (int64_t p = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; p < npix; p += (int64_t)gridDim.x * NTHREADS) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (sizeof(T) == 1) v[c] = prep_u8(in[p * 3 + c]);
+            else v[c] = in[p * 3 + c];
+        }
+        float* o = out + p * cpad;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+}
+
+// 3x3 pooling over NHWC, one thread per (output pixel, 4 channels); dst may be a channel slice of a wider tensor.
+// MAX: stride 2, VALID (inception_v3.py:111, :123, :229, :366).  AVG: stride 1, SAME, divided by the taps inside the image.
+template <bool MAX>
+__global__ __launch_bounds__(NTHREADS) void pool3x3_kernel(const float* __restrict__ in, float* __restrict__ out, int nimg, int hi, int wi,
+                                                           int c, int ho, int wo, int ldo) {
+    const int c4 = c >> 2;
+    const int64_t total = (int64_t)nimg * ho * wo * c4;
+    for (int64_t t = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; t < total; t += (int64_t)gridDim.x * NTHREADS) {
+        const int ch = (int)(t % c4) * 4;
+        int64_t r = t / c4;
+        const int x = (int)(r % wo); r /= wo;
+        const int y = (int)(r % ho);
+        const int n = (int)(r / ho);
+        const int s = MAX ? 2 : 1, off = MAX ? 0 : -1;
+        float4 a = MAX ? make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = y * s + ky + off, xx = x * s + kx + off;
+                if ((unsigned)yy >= (unsigned)hi || (unsigned)xx >= (unsigned)wi) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + (((int64_t)n * hi + yy) * wi + xx) * c + ch);
+                if (MAX) { a.x = fmaxf(a.x, v.x); a.y = fmaxf(a.y, v.y); a.z = fmaxf(a.z, v.z); a.w = fmaxf(a.w, v.w); }
+                else { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+                ++cnt;
+            }
+        if (!MAX) { const float inv = 1.f / (float)cnt; a.x *= inv; a.y *= inv; a.z *= inv; a.w *= inv; }
+        *reinterpret_cast<float4*>(out + (((int64_t)n * ho + y) * wo + x) * ldo + ch) = a;
+    }
+}
+
 static unsigned ew_blocks(int64_t work) {
     int64_t b = (work + NTHREADS - 1) / NTHREADS;
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+void pad_channels_u8(hipStream_t s, const uint8_t* in, float* out, int64_t npix, int cpad) {
+    hipLaunchKernelGGL((pad_channels_kernel<uint8_t>), dim3(ew_blocks(npix)), dim3(NTHREADS), 0, s, in, out, npix, cpad);
+}
+void pad_channels_f32(hipStream_t s, const float* in, float* out, int64_t npix, int cpad) {
+    hipLaunchKernelGGL((pad_channels_kernel<float>), dim3(ew_blocks(npix)), dim3(NTHREADS), 0, s, in, out, npix, cpad);
+}
+void maxpool3x3s2(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo) {
+    const int ho = (hi - 3) / 2 + 1, wo = (wi - 3) / 2 + 1;
+    hipLaunchKernelGGL((pool3x3_kernel<true>), dim3(ew_blocks((int64_t)nimg * ho * wo * (c / 4))), dim3(NTHREADS), 0, s, in, out, nimg, hi, wi, c, ho, wo, ldo);
+}
+void avgpool3x3s1(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo) {
+    hipLaunchKernelGGL((pool3x3_kernel<false>), dim3(ew_blocks((int64_t)nimg * hi * wi * (c / 4))), dim3(NTHREADS), 0, s, in, out, nimg, hi, wi, c, hi, wi, ldo);
 }
 
 void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n) {

@@ -46,6 +46,11 @@ void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* o
 
 // (x * 1/255 - 0.5) * 2 in unfused f32 ops (rllab/sampler/base.py:116-119)
 void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
+// Inception front end: 3-channel frames into a channel-padded buffer; 3x3 max (stride 2, VALID) / avg (stride 1, SAME) pooling
+void pad_channels_u8(hipStream_t s, const uint8_t* in, float* out, int64_t npix, int cpad);
+void pad_channels_f32(hipStream_t s, const float* in, float* out, int64_t npix, int cpad);
+void maxpool3x3s2(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo);
+void avgpool3x3s1(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo);
 // out[r] = in[r % nrows_in] -- the [context]*batch_size broadcast of base.py:217-218
 void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows);
 

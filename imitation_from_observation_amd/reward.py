@@ -27,11 +27,21 @@ class TranslatorReward:
 
     @classmethod
     def for_sampler(cls, name, imsize, nvp, scale, modelname=None, ablation_type="None", batch_size=25,
-                    paths_per_launch=10, device=0):
+                    paths_per_launch=10, device=0, mode="ours", inception_ckpt=None):
         """What BaseSampler.initialize() sets up for mode 'ours' (base.py:113-145): the model class follows the
         experiment name -- ContextAEReal for 'real'/'sweep', ContextSkipNew otherwise (:134-137) -- on the
-        sampler's imsize, restored from `modelname` when given (:138)."""
+        sampler's imsize, restored from `modelname` when given (:138).  mode 'oursinception' (:121-132): frames go
+        through the frozen Inception-v3 (variables from `inception_ckpt`, an .npz keyed by the TF names) and
+        ContextAEInception2 runs on the Mixed_7c feature maps."""
         from .translator import Translator
+        if mode == "oursinception":
+            from .oursinception import InceptionTranslator
+            it = InceptionTranslator(imsize, max_batch=batch_size * paths_per_launch, device=device)
+            if inception_ckpt is not None:
+                it.front.load(inception_ckpt)
+            if modelname is not None:
+                it.tr.load(modelname)
+            return cls(it, nvp, scale, name=name, ablation_type=ablation_type, batch_size=batch_size)
         real = name in ("real", "sweep")
         tr = Translator(imsize[0], imsize[1], featsize=100 if real else 1024, max_batch=batch_size * paths_per_launch,
                         device=device, variant="real" if real else "skipnew")
@@ -65,14 +75,15 @@ class TranslatorReward:
         for vp in range(self.nvp):
             ctx = np.ascontiguousarray(first_frames[vp], dtype=np.uint8)
             fsum = np.zeros((bs, self.tr.featsize), np.float64)
-            isum = np.zeros((bs, self.tr.H, self.tr.W, 3), np.float64)
+            pshape = tuple(getattr(self.tr, "pred_shape", (self.tr.H, self.tr.W, 3)))   # feature maps in mode 'oursinception'
+            isum = np.zeros((bs,) + pshape, np.float64)
             for i0 in range(0, len(mine), per_call):
                 vids = mine[i0:i0 + per_call]
                 # ((validdata[::skip, i] + 1) * 127.5).astype(np.uint8), base.py:215
                 u8 = np.concatenate([((validdata[::self.skip, i][:bs] + 1) * 127.5).astype(np.uint8) for i in vids])
                 timg, tfeat = self.tr.translate(u8, ctx)                   # [translated_z, out], base.py:216-218
                 fsum += tfeat.reshape(len(vids), bs, -1).sum(0)
-                isum += timg.reshape(len(vids), bs, self.tr.H, self.tr.W, 3).sum(0)
+                isum += timg.reshape((len(vids), bs) + pshape).sum(0)
             if distributed and world > 1:
                 flat = torch.from_numpy(np.concatenate([fsum.ravel(), isum.ravel()]))
                 if dist.get_backend() == "nccl":

@@ -191,6 +191,41 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
  * parity tests only; names are listed in csrc/ctxtrans.cpp). */
 int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n);
 
+/* ---- frozen conv-net front end (mode 'oursinception') --------------------------------------------
+ * Replaces the reference's  inception_v3.inception_v3(images, is_training=False)[1]['Mixed_7c']
+ * (rllab/sampler/base.py:122-127, scripts/train_script.py:104-111; nets/inception_v3.py:93-416).  The graph is
+ * handed over as an op list by the host (imitation_from_observation_amd/inception_frontend.py builds it from the
+ * reference's layer table); this library executes it.  Activations are NHWC, channel counts rounded up to 32.
+ *   CONV     slim.conv2d: kh x kw (kh*kw <= 25) conv, stride 1|2, TF 'SAME' or 'VALID', with the batch norm folded by the
+ *            host into the filter  w' = w / sqrt(var + 0.001)  and a bias  b' = beta - mean / sqrt(var + 0.001),  then ReLU;
+ *            filter [kh][kw][src channels (padded)][cout] at w_off, bias [cout] at b_off (floats into the blob);
+ *            output written to channels [dst_ch0, dst_ch0 + cout) of buffer dst (tf.concat = adjacent slices).
+ *   MAXPOOL  3x3 stride 2 VALID.     AVGPOOL  3x3 stride 1 SAME, mean over the taps inside the image.
+ * Buffer 0 is the frame buffer (h, w, 32: channels 0..2 hold the frame); the LAST buffer is the output. */
+enum { CTX_CNN_CONV = 0, CTX_CNN_MAXPOOL = 1, CTX_CNN_AVGPOOL = 2 };
+typedef struct ctx_cnn_buf { int32_t h, w, c; } ctx_cnn_buf;
+typedef struct ctx_cnn_op {
+    int32_t kind, src, dst, dst_ch0;
+    int32_t kh, kw, stride, same;     /* CONV only; same: 1 = 'SAME', 0 = 'VALID' */
+    int32_t cout, reserved;
+    int64_t w_off, b_off;
+} ctx_cnn_op;
+typedef struct ctx_cnn ctx_cnn;
+int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, int nops, int64_t weight_floats,
+                   int max_images, int precision, int device, void* stream, ctx_cnn** out);
+void ctx_cnn_destroy(ctx_cnn* h);
+const char* ctx_cnn_last_error(const ctx_cnn* h);          /* h == NULL: last creation error of this thread */
+int ctx_cnn_set_weights(ctx_cnn* h, const float* blob, size_t n);
+/* frames: host uint8 [n,H,W,3], preprocessed like base.py:116-119; out: host f32 [n,h,w,c] of the last buffer.
+ * n may exceed max_images (processed in chunks). */
+int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out);
+/* d_frames: DEVICE f32 [n,H,W,3] in [-1,1], n <= max_images; *d_out: device pointer of the last buffer.
+ * Asynchronous on the handle's stream (ctx_cnn_stream / ctx_cnn_sync). */
+int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** d_out);
+int ctx_cnn_read_buffer(ctx_cnn* h, int index, int n, float* out);   /* end-point tests */
+void* ctx_cnn_stream(ctx_cnn* h);
+int ctx_cnn_sync(ctx_cnn* h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,101 @@
+"""The Inception-v3 front end (imitation_from_observation_amd/inception_frontend.py + csrc/cnn.cpp).
+CPU: the op-list layout against what the reference's test holds (end-point shapes, variable total).
+GPU: every end point against oracle/inception_oracle.py on the same synthetic variables."""
+import numpy as np
+import pytest
+
+from imitation_from_observation_amd.inception_frontend import _Layout
+from oracle import inception_oracle as io
+from tests.test_oracle_inception import REF_SHAPES
+
+
+def test_layout_matches_reference_endpoints_and_variable_total():
+    lay = _Layout(299, 299)
+    assert list(lay.endpoints) == list(REF_SHAPES)
+    for k, v in REF_SHAPES.items():
+        assert lay.endpoints[k][1:] == v, k                                   # nets/inception_v3_test.py:87-104
+    assert sum(int(np.prod(c["k"])) * c["cin"] * c["cout"] + 3 * c["cout"] for c in lay.convs) == 21802784     # :120
+    # same variables, same order of creation, as the oracle's walk of the reference graph
+    names = [c["scope"] for c in lay.convs]
+    assert names == [n[:-len("/weights")] for n, _ in io.param_specs() if n.endswith("/weights")]
+    # every concat is a set of adjacent, non-overlapping channel slices that tile the block output
+    by_dst = {}
+    for op in lay.ops:
+        width = op["cout"] if op["kind"] == 0 else lay.bufs[op["src"]][2]
+        by_dst.setdefault(op["dst"], []).append((op["dst_ch0"], op["dst_ch0"] + width))
+    for name in ("Mixed_5b", "Mixed_6a", "Mixed_6e", "Mixed_7a", "Mixed_7c"):
+        bid, _, _, c = lay.endpoints[name]
+        sl = sorted(by_dst[bid])
+        assert sl[0][0] == 0 and sl[-1][1] == c and all(a[1] == b[0] for a, b in zip(sl, sl[1:])), name
+    assert _Layout(125, 125).out[1:] == (2, 2, 2048)
+
+
+@pytest.fixture(scope="module")
+def front():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd.inception_frontend import InceptionFrontend
+    f = InceptionFrontend(125, 125, max_images=3)
+    tree = f.init_synthetic(0)
+    yield f, {k: v.astype(np.float64) for k, v in tree.items()}
+    f.close()
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.gpu
+def test_every_endpoint_matches_the_oracle(front):
+    from oracle.ctx_oracle import preprocess_u8
+    f, p = front
+    rng = np.random.default_rng(0)
+    u8 = rng.integers(0, 256, (2, 125, 125, 3), dtype=np.uint8)
+    feat = f.features(u8)
+    ref = io.forward(p, preprocess_u8(u8).astype(np.float64))
+    assert feat.shape == (2, 2, 2, 2048)
+    for name, r in ref.items():
+        got = f.endpoint(name, 2)
+        assert got.shape == r.shape, name
+        assert relmax(got, r) < 1e-4, name                                   # fp32 through <= 47 conv layers: ~1e-6
+    np.testing.assert_array_equal(feat, f.endpoint("Mixed_7c", 2))
+    assert relmax(feat, ref["Mixed_7c"]) < 1e-4
+
+
+@pytest.mark.gpu
+def test_chunking_device_entry_and_padding_stay_clean(front):
+    import torch
+    from oracle.ctx_oracle import preprocess_u8
+    f, p = front
+    rng = np.random.default_rng(1)
+    u8 = rng.integers(0, 256, (7, 125, 125, 3), dtype=np.uint8)            # 7 > max_images = 3: three passes
+    feat = f.features(u8)
+    one = np.concatenate([f.features(u8[i:i + 1]) for i in range(7)])
+    np.testing.assert_array_equal(feat, one)                                 # per-image independent, bit for bit
+    x = torch.from_numpy(preprocess_u8(u8[:3])).cuda()
+    torch.cuda.synchronize()
+    d = f.features_dev(x.data_ptr(), 3)
+    f.sync()
+    assert d
+    np.testing.assert_array_equal(f.endpoint("Mixed_7c", 3), feat[:3])
+    # padded channels (80 -> 96) were never written
+    bid = f.endpoints["Conv2d_3b_1x1"][0]
+    raw = np.empty((3,) + f._bufs[bid], np.float32)
+    import ctypes
+    f._ck(f._lib.ctx_cnn_read_buffer(f._h, bid, 3, raw.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    assert not raw[..., 80:].any() and raw[..., :80].any()
+
+
+@pytest.mark.gpu
+def test_split_precision_front_end():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd.inception_frontend import InceptionFrontend
+    from oracle.ctx_oracle import preprocess_u8
+    with InceptionFrontend(125, 125, max_images=2, precision="bf16x3") as f:
+        p = {k: v.astype(np.float64) for k, v in f.init_synthetic(3).items()}
+        u8 = np.random.default_rng(2).integers(0, 256, (2, 125, 125, 3), dtype=np.uint8)
+        assert relmax(f.features(u8), io.forward(p, preprocess_u8(u8).astype(np.float64))["Mixed_7c"]) < 1e-3

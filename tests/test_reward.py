@@ -215,3 +215,50 @@ def test_sweep_hook_uses_context_ae_real_on_36x64():
     np.testing.assert_allclose(c, cref, rtol=1e-3)
     for a, b in zip(paths2, paths):
         np.testing.assert_allclose(a["rewards"], b["rewards"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_oursinception_hook_matches_oracle_composition():
+    """mode 'oursinception' (base.py:121-132): frames -> Inception-v3 -> ContextAEInception2, against the two oracles
+    composed on the CPU.  Synthetic variables for both nets (the reference tree holds neither checkpoint)."""
+    import copy
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from oracle import ctx_oracle_incep as oi
+    from oracle import inception_oracle as io
+    rng = np.random.default_rng(11)
+    bs, S = 5, 125
+    hook = TranslatorReward.for_sampler("strike", (S, S), nvp=1, scale=0.01, batch_size=bs, paths_per_launch=2, mode="oursinception")
+    it = hook.tr
+    ip = {k: v.astype(np.float64) for k, v in it.front.init_synthetic(4).items()}
+    cfg = oi.Incep2Config()
+    tp = oi.init_params(cfg, 9, np.float32, stddev=0.01)
+    it.tr.set_params(tp)
+    tp64 = {k: v.astype(np.float64) for k, v in tp.items()}
+    validdata = rng.uniform(-1, 1, (bs, 3, S, S, 3)).astype(np.float32)
+    paths = []
+    for _ in range(3):
+        imgs = [None if t % 2 == 0 else [rng.integers(0, 256, (S, S, 3), dtype=np.uint8)] for t in range(2 * bs)]
+        paths.append({"rewards": rng.standard_normal(2 * bs), "env_infos": {"imgs": imgs}})
+    first = paths[0]["env_infos"]["imgs"][1]
+
+    def feats(u8):
+        return io.forward(ip, o.preprocess_u8(u8).astype(np.float64))["Mixed_7c"]
+
+    class Composed:
+        max_batch, H, W, featsize, pred_shape = 2 * bs, S, S, 1024, (2, 2, 2048)
+        def translate(self, src, ctx0):
+            f = feats(np.concatenate([src, ctx0[None]]))
+            return oi.translate(tp64, f[:-1], f[-1], cfg)
+        def encode(self, frames, return_frames=True):
+            f = feats(frames)
+            return oi.encode(tp64, f, cfg), f
+
+    paths2 = copy.deepcopy(paths)
+    cref = TranslatorReward(Composed(), 1, 0.01, batch_size=bs).build_demo_cache(validdata, first).process_paths(paths)
+    c = hook.build_demo_cache(validdata, first).process_paths(paths2)
+    it.close()
+    np.testing.assert_allclose(c, cref, rtol=1e-3)
+    for a, b in zip(paths2, paths):
+        np.testing.assert_allclose(a["rewards"], b["rewards"], rtol=1e-3, atol=1e-5)
