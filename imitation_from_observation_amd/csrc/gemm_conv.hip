@@ -6,19 +6,19 @@ void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, i
     NmPlain b = b_;
     b.seglen = a.tap_outer ? 0 : a.cps * KC;     // filter rows in KmConvGather's K order (A/B measured: no difference)
     b.ntap = a.ntaps();
-    launch_igemm<KmConvGather, NmPlain, true>(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
+    launch_igemm<KmConvGather, NmPlain, true, 1, 0>(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     ep.rowmode = 1; ep.hs = a.hs; ep.ws = a.ws;
     // no split-K here: the four parity classes have different K extents and M is the pixel count
-    launch_igemm<KmConvTGather, KmConvTWeights, true>(s, a, b, ep, M, N, 4, 0, ws);
+    launch_igemm<KmConvTGather, KmConvTWeights, true, 2, 2>(s, a, b, ep, M, N, 4, 0, ws);
 }
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws) {
     // B[k][n] = w[ky,kx,c,k] with n = (ky*5+kx)*3+c: the filter itself, rows n contiguous in k
     KmPlain b{w, cb, nullptr, 0, cb, 75, cb / KC, a.zeros};
     Epi ep;
     ep.out1 = P; ep.ld1 = P3_LD;
-    launch_igemm(s, a, b, ep, M, 75, 1, 0, ws);
+    launch_igemm<KmCat2, KmPlain, false, 1, 2>(s, a, b, ep, M, 75, 1, 0, ws);
 }
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);

@@ -25,8 +25,7 @@ static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, const Epi
 }
 
 template <class LA, class LB, int MI, int NI, int WM, int WN>
-static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit, int prec = 0) {
-    if (prec) { launch_tile_split<LA, LB, MI, NI, WM, WN>(s, a, b, ep, M, N, nprob, nsplit); return; }
+static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
     constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM, NT>::FLOATS + Tile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
@@ -41,7 +40,29 @@ static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, 
 }
 
 // BIG = the 8-wave 256x256 tile is instantiated for this loader pair
-template <class LA, class LB, bool BIG = false>
+template <class LA, class LB, int MI, int NI, int WM, int WN>
+static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit, int prec) {
+    if (prec) launch_tile_split<LA, LB, MI, NI, WM, WN>(s, a, b, ep, M, N, nprob, nsplit);
+    else launch_tile_f32<LA, LB, MI, NI, WM, WN>(s, a, b, ep, M, N, nprob, nsplit);
+}
+
+// The 128x128 block tile comes in three wave layouts: W = 0: 4 waves of 64x64; 1: 8 waves of 64x32; 2: 8 waves of 32x64.
+// Eight waves (4 per SIMD at two blocks per CU) hide more of the load latency: measured per loader pair and precision at
+// B = 256 (f32: -6..-20 % everywhere; bf16x3: the conv gather prefers 4 waves), so each launcher names its pair's choice.
+template <class LA, class LB, int W, bool SPLIT>
+static void launch_128(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+    if constexpr (SPLIT) {
+        if constexpr (W == 1) launch_tile_split<LA, LB, 2, 1, 2, 4>(s, a, b, ep, M, N, nprob, nsplit);
+        else if constexpr (W == 2) launch_tile_split<LA, LB, 1, 2, 4, 2>(s, a, b, ep, M, N, nprob, nsplit);
+        else launch_tile_split<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    } else {
+        if constexpr (W == 1) launch_tile_f32<LA, LB, 2, 1, 2, 4>(s, a, b, ep, M, N, nprob, nsplit);
+        else if constexpr (W == 2) launch_tile_f32<LA, LB, 1, 2, 4, 2>(s, a, b, ep, M, N, nprob, nsplit);
+        else launch_tile_f32<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    }
+}
+
+template <class LA, class LB, bool BIG = false, int W32 = 1, int WSP = 0>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
                          SplitWs ws) {
     static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
@@ -79,7 +100,10 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
-    if (MI == 2 && NI == 2) launch_tile<LA, LB, 2, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
+    if (MI == 2 && NI == 2) {
+        if (ws.prec) launch_128<LA, LB, WSP, true>(s, a, b, ep, M, N, nprob, nsplit);
+        else launch_128<LA, LB, W32, false>(s, a, b, ep, M, N, nprob, nsplit);
+    }
     else if (MI == 2) launch_tile<LA, LB, 2, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
     else if (NI == 2) launch_tile<LA, LB, 1, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
     else launch_tile<LA, LB, 1, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);

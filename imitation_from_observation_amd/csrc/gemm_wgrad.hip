@@ -1,17 +1,19 @@
 // filter gradients of conv2d / conv2d_transpose: 25 taps = 25 problems, reduction over pixels
+#include <type_traits>
+
 #include "gemm_launch.h"
 namespace ctx {
 void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
+    launch_igemm<NmWgradBig, std::remove_cv_t<std::remove_reference_t<decltype(b)>>, false, 1, 2>(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
 }
 void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
+    launch_igemm<NmWgradBigP, std::remove_cv_t<std::remove_reference_t<decltype(b)>>, false, 1, 2>(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
 }
 void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
+    launch_igemm<NmWgradBigP, std::remove_cv_t<std::remove_reference_t<decltype(b)>>, false, 1, 2>(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
 }
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
@@ -19,7 +21,7 @@ void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Ep
 }
 void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
-    launch_igemm(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
+    launch_igemm<NmWgradBig, std::remove_cv_t<std::remove_reference_t<decltype(b)>>, false, 1, 2>(s, a, b, ep, M, N, a.K * a.K, (a.npix + KC - 1) / KC, ws);
 }
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;

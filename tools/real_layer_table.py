@@ -1,0 +1,13 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo')
+from imitation_from_observation_amd import Translator
+B=256
+g=torch.Generator(device="cuda").manual_seed(0)
+fr=[torch.rand((B,36,64,3),device="cuda",generator=g)*2-1 for _ in range(3)]
+with Translator(36,64,featsize=100,max_batch=B,variant="real") as tr:
+    tr.init_params(0)
+    ents=tr.profile_step(*(t.data_ptr() for t in fr), B, iters=3)
+    tot=sum(e["ms"] for e in ents)
+    print("total", tot)
+    for e in sorted(ents, key=lambda e:-e["ms"])[:25]:
+        print(f"{e['name']:32s} {e['kernel']:34s} {e['ms']:8.3f} ms {e['flops']/e['ms']/1e9 if e['ms'] else 0:7.1f} TF/s(padded)")
