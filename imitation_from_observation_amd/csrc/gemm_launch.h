@@ -104,6 +104,9 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         if (ws.prec) launch_128<LA, LB, WSP, true>(s, a, b, ep, M, N, nprob, nsplit);
         else launch_128<LA, LB, W32, false>(s, a, b, ep, M, N, nprob, nsplit);
     }
+    // 128x64 / 64x128: eight 32x32 waves in f32 (-3 % of a step); the split tile needs >= 2 loads per thread, so 4 waves there
+    else if (MI == 2 && !ws.prec) launch_tile_f32<LA, LB, 1, 1, 4, 2>(s, a, b, ep, M, N, nprob, nsplit);
+    else if (NI == 2 && !ws.prec) launch_tile_f32<LA, LB, 1, 1, 2, 4>(s, a, b, ep, M, N, nprob, nsplit);
     else if (MI == 2) launch_tile<LA, LB, 2, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
     else if (NI == 2) launch_tile<LA, LB, 1, 2, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
     else launch_tile<LA, LB, 1, 1, 2, 2>(s, a, b, ep, M, N, nprob, nsplit, ws.prec);
