@@ -100,7 +100,11 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
-    if (MI == 2 && NI == 2) {
+    // narrow operands (ContextAEReal's 32-channel layers): tiles that do not multiply zeros.  f32 only.
+    if (!ws.prec && N <= 32 && M > 64) launch_tile_f32<LA, LB, 1, 1, 4, 1>(s, a, b, ep, M, N, nprob, nsplit);          // 128 x 32
+    else if (!ws.prec && N <= 32 && M <= 32) launch_tile_f32<LA, LB, 1, 1, 1, 1>(s, a, b, ep, M, N, nprob, nsplit);    //  32 x 32
+    else if (!ws.prec && M <= 32 && N <= 64) launch_tile_f32<LA, LB, 1, 1, 1, 2>(s, a, b, ep, M, N, nprob, nsplit);    //  32 x 64
+    else if (MI == 2 && NI == 2) {
         if (ws.prec) launch_128<LA, LB, WSP, true>(s, a, b, ep, M, N, nprob, nsplit);
         else launch_128<LA, LB, W32, false>(s, a, b, ep, M, N, nprob, nsplit);
     }
