@@ -156,8 +156,8 @@ def main():
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
         # figure comes from the committed rocprofv3 --pmc passes of the same workload (profiles/*_hbm_traffic.json)
         import glob
-        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
-        if prof and B == 256 and args.precision == "f32":
+        prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json" if args.precision == "f32" else f"*_hbm_traffic_{args.precision}.json")))
+        if prof and B == 256:
             with open(prof[-1]) as f:
                 tr_json = json.load(f)
             ent = tr_json["per_kernel"].get(kname)
