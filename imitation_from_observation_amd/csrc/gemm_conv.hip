@@ -10,8 +10,11 @@ void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, i
 }
 void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     ep.rowmode = 1; ep.hs = a.hs; ep.ws = a.ws;
-    // no split-K here: the four parity classes have different K extents and M is the pixel count
-    launch_igemm<KmConvTGather, KmConvTWeights, true, 2, 2>(s, a, b, ep, M, N, 4, 0, ws);
+    // the four parity classes have different K extents (4/6/6/9 taps for k 5); each class is split into the same number of
+    // parts, and the cost model sees the shortest class (small grids -- the 4x4 and 8x8 layers -- do not fill the chip otherwise)
+    const int par = a.pb & 1, tmin = ((a.K - (1 - par) + 1) / 2) * ((a.K - (1 - par) + 1) / 2);
+    static const bool sk = [] { const char* e = getenv("CTX_CONVT_SPLITK"); return !(e && e[0] == '0'); }();
+    launch_igemm<KmConvTGather, KmConvTWeights, true, 2, 2>(s, a, b, ep, M, N, 4, sk ? tmin * a.cps : 0, ws);
 }
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws) {
     // B[k][n] = w[ky,kx,c,k] with n = (ky*5+kx)*3+c: the filter itself, rows n contiguous in k

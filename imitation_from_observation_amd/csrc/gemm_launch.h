@@ -68,7 +68,8 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
     if constexpr (BIG) {
         const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
-        if (force != 1 && M >= 256 && N >= 256 && (big_tiles >= 192 || force == 2)) {
+        // (since the 128x128 tile runs eight waves the 256x256 tile only pays in the split-bf16 mode: f32 conv gather -2.4 % without it)
+        if (force != 1 && M >= 256 && N >= 256 && ((big_tiles >= 192 && ws.prec) || force == 2)) {
             ep.slab = nullptr;
             launch_tile<LA, LB, 2, 4, 4, 2>(s, a, b, ep, M, N, nprob, 1, ws.prec);
             return;
