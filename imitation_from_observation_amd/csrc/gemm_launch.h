@@ -47,6 +47,7 @@ static void launch_tile(hipStream_t s, const LA& a, const LB& b, const Epi& ep, 
 }
 
 // The 128x128 block tile comes in three wave layouts: W = 0: 4 waves of 64x64; 1: 8 waves of 64x32; 2: 8 waves of 32x64.
+// (a 16-wave 256x128 / 128x256 tile, one block per CU, was measured too: +3..+14 % time; not kept.)
 // Eight waves (4 per SIMD at two blocks per CU) hide more of the load latency: measured per loader pair and precision at
 // B = 256 (f32: -6..-20 % everywhere; bf16x3: the conv gather prefers 4 waves), so each launcher names its pair's choice.
 template <class LA, class LB, int W, bool SPLIT>
