@@ -74,6 +74,7 @@ struct ctx_handle {
     // buffers (see header comment)
     uint8_t* u8 = nullptr;
     float *img = nullptr, *Z = nullptr, *dZ = nullptr;
+    float *img4 = nullptr, *dout4 = nullptr;   // 4-channel copies of img / dout for the cin = 3 loaders (C == 3 only)
     float *s[5] = {}, *c[5] = {}, *cz = nullptr, *th0 = nullptr;     // s[k], c[k]: h0..h3 conv outputs, [4] = h4
     float *dz = nullptr, *e[4] = {}, *out = nullptr;                 // e[1..3] decoder activations
     float *dout = nullptr, *dE[4] = {}, *dSk[4] = {}, *dDz = nullptr, *dsim2 = nullptr;
@@ -266,6 +267,7 @@ int alloc_buffers(ctx_handle* h) {
     const int64_t B = h->Bm, d = h->d, F = h->F;
     TRY(dev_alloc(h, &h->u8, 3 * B * h->npi));
     TRY(dev_alloc(h, &h->img, 3 * B * h->npi));
+    TRY(dev_alloc(h, &h->img4, 3 * B * h->npi / 3 * 4));
     TRY(dev_alloc(h, &h->Z, 3 * B * F));
     TRY(dev_alloc(h, &h->dZ, 3 * B * F));
     for (int k = 0; k < 4; ++k) {
@@ -295,6 +297,7 @@ int alloc_buffers(ctx_handle* h) {
     TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
     TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD));
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
+    TRY(dev_alloc(h, &h->dout4, 2 * B * h->npi / 3 * 4));
     int64_t maxc = std::max<int64_t>(h->D0, F);
     maxc = std::max<int64_t>(maxc, 16 * d);
     TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
@@ -309,6 +312,14 @@ int alloc_buffers(ctx_handle* h) {
     if (hipMemset(h->zeros, 0, 64 * sizeof(float)) != hipSuccess) return fail(h, CTX_E_DEVICE, "hipMemset(zeros)");
     return CTX_OK;
 }
+
+// the 4-channel copy of a pointer into img / dout (cin = 3 loaders); pack_c4 refreshes `npix` pixels of it
+const float* c4of(const ctx_handle* h, const float* p3) {
+    const int64_t ni = 3 * (int64_t)h->Bm * h->npi;
+    if (p3 >= h->img && p3 < h->img + ni) return h->img4 + (p3 - h->img) / 3 * 4;
+    return h->dout4 + (p3 - h->dout) / 3 * 4;
+}
+void pack_c4(ctx_handle* h, const float* p3, int64_t npix) { pack3to4(h->stream, p3, const_cast<float*>(c4of(h, p3)), npix); }
 
 SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.precision}; }
 
@@ -377,7 +388,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
-    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{x, hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
+    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
     else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
 
@@ -468,6 +479,9 @@ void forward(ctx_handle* h, int B, Mode mode) {
     const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
     float* src_z = h->Z + 2ll * B * F;
     const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
+    // refresh the 4-channel copy of the frames in use (what the cin = 3 loaders read)
+    if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
+    else pack_c4(h, h->img + B * npi, (mode == MODE_ENCODE ? 1ll : 2ll) * B * h->H * h->W);
     if (lanes) {
         fork(h, LANE_CTX);
         LaneSwap sw(h, LANE_CTX);
@@ -525,6 +539,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     {
         ProfScope ps(h, "losses", K_EW, 0.0);
         losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+        pack_c4(h, h->dout, 2ll * B * h->H * h->W);
     }
 
     // ---- decoder, both passes at once (batch 2B)
@@ -550,8 +565,8 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         if (ca == 3) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
-              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{dy, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
-            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(h->stream, KmC3Gather{dy, hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
+              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{c4of(h, dy), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(h->stream, KmC3Gather{c4of(h, dy), hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
         } else {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
@@ -615,7 +630,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 Side sd(h, dw_lane);
                 bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
-                conv3_wgrad(h->stream, NmC3WgradBig{xin, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
+                conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 break;   // no gradient w.r.t. the frame
             }
             { Side sd(h, dw_lane);

@@ -27,6 +27,6 @@ void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, E
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
-    launch_igemm(s, a, b, ep, M, N, 1, 3, ws);
+    launch_igemm(s, a, b, ep, M, N, 1, 4, ws);
 }
 }  // namespace ctx

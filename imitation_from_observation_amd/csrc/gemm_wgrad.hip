@@ -17,7 +17,7 @@ void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b,
 }
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
-    launch_igemm(s, a, b, ep, 80, N, 1, (a.npix + KC - 1) / KC, ws);
+    launch_igemm(s, a, b, ep, 100, N, 1, (a.npix + KC - 1) / KC, ws);
 }
 void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N;
@@ -25,6 +25,6 @@ void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi
 }
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
-    launch_igemm(s, a, b, ep, 80, N, 1, (a.npix + KC - 1) / KC, ws);
+    launch_igemm(s, a, b, ep, 100, N, 1, (a.npix + KC - 1) / KC, ws);
 }
 }  // namespace ctx

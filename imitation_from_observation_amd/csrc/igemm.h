@@ -108,7 +108,7 @@ struct Epi {
     const float* mask = nullptr;    // saved lrelu OUTPUT; v *= (mask >= 0 ? 1 : 0.2) for n < nsplit
     int64_t ldm = 0;
     int lrelu = 0;                  // 1: v = max(v, 0.2 v) after bias/adds; 2: plain ReLU (the Inception front end)
-    int rowmode = 0;                // 0: pix = m; 1: transposed-conv parity class; 2: (ky,e) rows of a C=3 filter
+    int rowmode = 0;                // 0: pix = m; 1: transposed-conv parity class; 2: rows m = tap*4+ch of a C=3 filter gradient
     int hs = 0, ws = 0;             // rowmode 1: small-grid size
     int64_t prob_stride = 0;        // out1 += prob * prob_stride (filter gradient: one tap per problem)
     float* slab = nullptr;          // split-K: raw partials to slab[((split*nprob+prob)*M + m)*N + n]
@@ -123,9 +123,9 @@ __device__ __forceinline__ bool epi_row(const Epi& e, int prob, int m, int64_t& 
         pix = ((int64_t)n * (2 * e.hs) + 2 * i + py) * (2 * e.ws) + 2 * j + px;
         return true;
     }
-    const int ky = m >> 4, el = m & 15;
-    if (ky >= 5 || el == 15) return false;
-    pix = ky * 15 + el;
+    const int tap = m >> 2, ch = m & 3;
+    if (tap >= 25 || ch == 3) return false;
+    pix = tap * 3 + ch;
     return true;
 }
 
@@ -365,39 +365,31 @@ struct KmCat2 {
     __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v2 : c.v1); }
 };
 
-// conv2d forward operand when cin == 3 (the frame itself, or the decoder's output gradient): for a
-// fixed ky the 5 taps x 3 channels of a row are 15 CONTIGUOUS floats starting at pixel (.., 2j-1).
-// A chunk holds two ky segments of 16 (15 + one zero); 3 chunks cover ky = 0..4.  (5 % of a step:
-// kept on scalar element loads with a zero page.)
+// cin == 3 operands (the frame itself, or d loss / d out of the 3-channel decoder output).  The tensor is read from
+// a 4-CHANNEL COPY x4[pixel][4] (channel 3 = 0; pack3to4_kernel) so that one tap of one pixel is ONE aligned
+// 16-byte load.  K order: k = tap * 4 + ch with the 25 taps padded to 32: 4 chunks of 8 taps, tap = 8 * chunk + k4 / 4.
 struct KmC3Gather {
     static constexpr bool KM = true;
-    const float* x;
+    const float* x4;
     int hb, wb, hs, ws;
     int R;
     const float* zeros;
     int s = 2, pad = 1;            // (1, 2) for the stride-1 layers of ContextAEReal
-    struct Pos { int chunk; };
-    struct Ctx { const float* base; int i2, j2, k4; bool ok; };   // base -> element (s*i-pad, s*j-pad, 0)
-    __device__ int nchunks_of(int) const { return 3; }
-    __device__ Pos pos(int, int chunk) const { return Pos{chunk}; }
+    struct Pos { rsrc_t rs; int tap0; };
+    struct Ctx { int pb, y0, x0, t8; };   // pb = pixel index of (s*i - pad, s*j - pad), may be negative; t8 < 0: row invalid
+    __device__ int nchunks_of(int) const { return 4; }
+    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(x4), 8 * chunk}; }
     __device__ void prep(int, int row, int k4, Ctx& c) const {
-        c.ok = row < R; c.k4 = k4;
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
-        c.i2 = s * i - pad; c.j2 = s * j - pad;
-        c.base = x + (((int64_t)n * hb + c.i2) * wb + c.j2) * 3;
+        c.y0 = s * i - pad; c.x0 = s * j - pad;
+        c.pb = (n * hb + c.y0) * wb + c.x0;
+        c.t8 = row < R ? (k4 >> 2) : -64;
     }
     __device__ float4 load(const Ctx& c, const Pos& q) const {
-        const int ky = 2 * q.chunk + (c.k4 >> 4);
-        const bool rowok = c.ok && ky < 5 && (unsigned)(c.i2 + ky) < (unsigned)hb;
-        const float* rowp = c.base + (int64_t)ky * wb * 3;
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int el = (c.k4 & 15) + u;        // (kx, ch) = (el / 3, el % 3)
-            const bool ok = rowok && el < 15 && (unsigned)(c.j2 + el / 3) < (unsigned)wb;
-            v[u] = *(ok ? rowp + el : zeros);
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
+        const int tap = q.tap0 + c.t8;
+        const int ky = (tap * 13) >> 6, kx = tap - 5 * ky;       // tap / 5 for 0 <= tap < 32
+        const bool ok = (unsigned)tap < 25u && (unsigned)(c.y0 + ky) < (unsigned)hb && (unsigned)(c.x0 + kx) < (unsigned)wb;
+        return bload4(q.rs, ok ? (uint32_t)(c.pb + ky * wb + kx) * 16u : OOB);
     }
 };
 
@@ -461,19 +453,20 @@ struct NmPlain2 {
     }
 };
 
-// cin == 3 conv filter as the B operand of KmC3Gather: k = (ky, el) with el = kx*3 + ch < 15.
+// cin == 3 conv filter w[5][5][3][cb] as the B operand of KmC3Gather: k = tap * 4 + ch -> filter row tap * 3 + ch (ch < 3).
 struct NmC3Weights {
     static constexpr bool KM = false;
     const float* w; int cb;
     const float* zeros;
-    struct Pos { int chunk; };
-    struct Ctx { int kk, r4; };
-    __device__ Pos pos(int, int chunk) const { return Pos{chunk}; }
-    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r4 = r4; }
-    __device__ float4 load(const Ctx& c, const Pos& q) const {
-        const int ky = 2 * q.chunk + (c.kk >> 4), el = c.kk & 15;
-        return ldg4_or0(w + (int64_t)(ky * 15 + el) * cb + c.r4, ky < 5 && el < 15 && c.r4 < cb, zeros);
+    struct Pos { rsrc_t rs; int tap0; };
+    struct Ctx { uint32_t v; int t; };
+    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(w + (int64_t)chunk * 24 * cb), 8 * chunk}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        const int t = kk >> 2, ch = kk & 3;
+        c.t = (ch < 3 && r4 < cb) ? t : 64;
+        c.v = (uint32_t)((t * 3 + ch) * cb + r4) * 4u;
     }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.tap0 + c.t < 25 ? c.v : OOB); }
 };
 
 // Filter-gradient operand: k = output-grid pixel (img,i,j); rows = channels of the BIG tensor at the
@@ -657,36 +650,33 @@ struct NmWgradSmall2P {
     }
 };
 
-// Filter gradient when the big tensor has 3 channels: rows m = ky*16 + el (el = kx*3+ch < 15).
+// Filter gradient when the big tensor has 3 channels (read from its 4-channel copy): rows m = tap * 4 + ch (100 of 128
+// used), k = output-grid pixel; a lane's float4 is the 4 channels of ONE tap at one pixel.
 struct NmC3WgradBig {
     static constexpr bool KM = false;
-    const float* big;
+    const float* big4;
     int hb, wb;
     PixDiv pd;
     int npix;
     const float* zeros;
     int s = 2, pad = 1;
-    struct Pos { int k0; };
-    struct Ctx { int kk, r4; };
+    struct Pos { rsrc_t rs; int k0; };
+    struct Ctx { int kk, dy, dx; };               // (dy, dx) = (ky - pad, kx - pad); dy = 1 << 20 marks a padded tap
     __device__ int nchunks_of(int) const { return (npix + KC - 1) / KC; }
-    __device__ Pos pos(int, int chunk) const { return Pos{chunk * KC}; }
-    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.kk = kk; c.r4 = r4; }
+    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(big4), chunk * KC}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        const int tap = r4 >> 2, ky = tap / 5, kx = tap - 5 * ky;
+        c.kk = kk;
+        c.dy = tap < 25 ? ky - pad : (1 << 20);
+        c.dx = kx - pad;
+    }
     __device__ float4 load(const Ctx& c, const Pos& q) const {
         const int p = q.k0 + c.kk;
-        const int ky = c.r4 >> 4;
         int n, i, j;
         pd.split(p, n, i, j);
-        const int y = s * i + ky - pad, j2 = s * j - pad;
-        const bool rowok = p < npix && ky < 5 && (unsigned)y < (unsigned)hb;
-        const float* rowp = big + ((((int64_t)n * hb + y) * wb) + j2) * 3;
-        float v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int el = (c.r4 & 15) + u;
-            const bool ok = rowok && el < 15 && (unsigned)(j2 + el / 3) < (unsigned)wb;
-            v[u] = *(ok ? rowp + el : zeros);
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
+        const int y = s * i + c.dy, xx = s * j + c.dx;
+        const bool ok = p < npix && (unsigned)y < (unsigned)hb && (unsigned)xx < (unsigned)wb;
+        return bload4(q.rs, ok ? (uint32_t)((n * hb + y) * wb + xx) * 16u : OOB);
     }
 };
 

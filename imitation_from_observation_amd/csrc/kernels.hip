@@ -168,11 +168,20 @@ __global__ __launch_bounds__(NTHREADS) void pool3x3_kernel(const float* __restri
     }
 }
 
+// [npix][3] -> [npix][4] with channel 3 = 0: the copy the cin = 3 loaders read (one aligned float4 per pixel)
+__global__ __launch_bounds__(NTHREADS) void pack3to4_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t npix) {
+    for (int64_t p = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; p < npix; p += (int64_t)gridDim.x * NTHREADS)
+        *reinterpret_cast<float4*>(out + 4 * p) = make_float4(in[3 * p], in[3 * p + 1], in[3 * p + 2], 0.f);
+}
+
 static unsigned ew_blocks(int64_t work) {
     int64_t b = (work + NTHREADS - 1) / NTHREADS;
     return (unsigned)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+void pack3to4(hipStream_t s, const float* in, float* out, int64_t npix) {
+    hipLaunchKernelGGL(pack3to4_kernel, dim3(ew_blocks(npix)), dim3(NTHREADS), 0, s, in, out, npix);
+}
 void pad_channels_u8(hipStream_t s, const uint8_t* in, float* out, int64_t npix, int cpad) {
     hipLaunchKernelGGL((pad_channels_kernel<uint8_t>), dim3(ew_blocks(npix)), dim3(NTHREADS), 0, s, in, out, npix, cpad);
 }

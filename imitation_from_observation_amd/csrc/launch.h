@@ -46,6 +46,7 @@ void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* o
 
 // (x * 1/255 - 0.5) * 2 in unfused f32 ops (rllab/sampler/base.py:116-119)
 void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n);
+void pack3to4(hipStream_t s, const float* in3, float* out4, int64_t npix);   // the 4-channel copy the cin = 3 loaders read
 // Inception front end: 3-channel frames into a channel-padded buffer; 3x3 max (stride 2, VALID) / avg (stride 1, SAME) pooling
 void pad_channels_u8(hipStream_t s, const uint8_t* in, float* out, int64_t npix, int cpad);
 void pad_channels_f32(hipStream_t s, const float* in, float* out, int64_t npix, int cpad);
