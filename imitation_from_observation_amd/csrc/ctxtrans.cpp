@@ -571,7 +571,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
               ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
-              if (patch_ok(hs, wsm)) {
+              if (rect_ok(2 * B) && rect_ok(B)) {
+                  const RectGeo rg = make_rect(2 * B, hs, wsm, hb, wb, 2, 1, 5);
+                  conv_wgrad2_r(h->stream, NmWgradBigR{dy, ca, ca, rg, g_zeros}, NmWgradSmall2R{dec_in, c1, c1, h->c[4 - k], c2, B, cb, rg, g_zeros}, eg, ca, cb, ws_of(h));
+              } else if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(2 * B, hs, wsm);
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
@@ -636,7 +639,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             { Side sd(h, dw_lane);
               bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
               ProfScope ps(h, ln + " dw", K_WGRAD, fl);
-              if (patch_ok(hs, wsm)) {
+              if (rect_ok(nimg)) {
+                  const RectGeo rg = make_rect(nimg, hs, wsm, hb, wb, 2, 1, 5);
+                  conv_wgrad_r(h->stream, NmWgradBigR{xin, ca, ca, rg, g_zeros}, NmWgradSmallR{dA[k], cb, cb, rg, g_zeros}, eg, ca, cb, ws_of(h));
+              } else if (patch_ok(hs, wsm)) {
                   const PatchGeo pg = make_patch(nimg, hs, wsm);
                   conv_wgrad_p(h->stream, NmWgradBigP{xin, ca, ca, wb, pg, g_zeros}, NmWgradSmallP{dA[k], cb, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad(h->stream, NmWgradBig{xin, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }

@@ -15,6 +15,20 @@ void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b,
     ep.prob_stride = (int64_t)M * N;
     launch_igemm<NmWgradBigP, std::remove_cv_t<std::remove_reference_t<decltype(b)>>, false, 1, 2>(s, a, b, ep, M, N, 25, ((a.g.rows_total + a.g.R - 1) / a.g.R) << a.g.ncol_sh, ws);
 }
+static int rect_avg_chunks(const RectGeo& g) {
+    int64_t t = 0;
+    for (int ky = 0; ky < g.K; ++ky)
+        for (int kx = 0; kx < g.K; ++kx) t += (int64_t)g.rh[ky] * g.rw[kx] * g.ipc;
+    return (int)(t / (g.K * g.K));
+}
+void conv_wgrad_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmallR& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.prob_stride = (int64_t)M * N;
+    launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
+}
+void conv_wgrad2_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmall2R& b, Epi ep, int M, int N, SplitWs ws) {
+    ep.prob_stride = (int64_t)M * N;
+    launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
+}
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
     launch_igemm(s, a, b, ep, 100, N, 1, (a.npix + KC - 1) / KC, ws);

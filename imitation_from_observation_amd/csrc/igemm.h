@@ -650,6 +650,115 @@ struct NmWgradSmall2P {
     }
 };
 
+// ---- rectangle-ordered filter gradient -----------------------------------------------------------------
+// K (the sum over output pixels and images) may be walked in any order.  For tap (ky,kx) only the output positions
+// whose input pixel (s*i+ky-pad, s*j+kx-pad) lies inside the big grid contribute -- a rectangle [i0,i0+rh) x [j0,j0+rw) --
+// and on the 4x4 / 8x8 grids the rest is 28 % / 14 % of all products (SAME-padding zeros).  Here K runs over that
+// rectangle only, position-major: k = ((i-i0)*rw + (j-j0)) * nimg + n.  With nimg a multiple of 32 a chunk is 32
+// images at ONE position: the position is wave-uniform (folded into the descriptor base) and a lane's offset
+// (image kk, channels r4) is loop-invariant, so a load is a single buffer_load with no per-chunk VALU at all.
+struct FastDiv {                     // x / d for 0 <= x < 2^31, d >= 1, by multiply-high (Granlund-Montgomery): no divider on the scalar unit
+    uint32_t mul; int sh;
+    __device__ __forceinline__ int div(int x) const { return (int)((__umulhi(mul, (uint32_t)x) + (uint32_t)x) >> sh); }
+};
+inline FastDiv make_fastdiv(int d) {
+    int sh = 0;
+    while ((1 << sh) < d) ++sh;
+    return FastDiv{(uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << sh) - (uint64_t)d)) / (uint64_t)d + 1), sh};
+}
+struct RectGeo {
+    int hs, ws, hb, wb, nimg, ipc;   // ipc = nimg / 32: chunks per position
+    int s, pad, K;
+    int i0[5], rh[5], j0[5], rw[5];  // per ky / per kx
+    FastDiv d_ipc, d_rw[5];
+    __device__ __forceinline__ int nchunks(int prob) const { const int ky = prob / K, kx = prob - ky * K; return rh[ky] * rw[kx] * ipc; }
+    // chunk -> output position (i, j), first image n0, and the tap
+    __device__ __forceinline__ void decode(int prob, int chunk, int& ky, int& kx, int& i, int& j, int& n0) const {
+        ky = prob / K; kx = prob - ky * K;
+        const int pos = d_ipc.div(chunk);
+        n0 = (chunk - pos * ipc) * KC;
+        const int r = d_rw[kx].div(pos);
+        i = i0[ky] + r; j = j0[kx] + (pos - r * rw[kx]);
+    }
+};
+inline bool rect_ok(int nimg) { return nimg > 0 && nimg % KC == 0; }
+inline RectGeo make_rect(int nimg, int hs, int ws, int hb, int wb, int s, int pad, int K) {
+    RectGeo g{};
+    g.hs = hs; g.ws = ws; g.hb = hb; g.wb = wb; g.nimg = nimg; g.ipc = nimg / KC; g.s = s; g.pad = pad; g.K = K;
+    auto range = [&](int k, int nbig, int nsmall, int& lo, int& len) {        // 0 <= s*i + k - pad < nbig
+        int a = 0, b = nsmall;
+        while (a < nsmall && s * a + k - pad < 0) ++a;
+        while (b > a && s * (b - 1) + k - pad >= nbig) --b;
+        lo = a; len = b - a;
+    };
+    for (int k = 0; k < 5; ++k) {
+        if (k < K) { range(k, hb, hs, g.i0[k], g.rh[k]); range(k, wb, ws, g.j0[k], g.rw[k]); }
+        else { g.i0[k] = g.j0[k] = 0; g.rh[k] = g.rw[k] = 0; }
+        g.d_rw[k] = make_fastdiv(g.rw[k] > 0 ? g.rw[k] : 1);
+    }
+    g.d_ipc = make_fastdiv(g.ipc);
+    return g;
+}
+
+struct NmWgradBigR {
+    static constexpr bool KM = false;
+    const float* big; int64_t ldb; int ca;
+    RectGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
+    __device__ Pos pos(int prob, int chunk) const {
+        int ky, kx, i, j, n0;
+        g.decode(prob, chunk, ky, kx, i, j, n0);
+        return Pos{make_rsrc(big + (((int64_t)n0 * g.hb + (g.s * i + ky - g.pad)) * g.wb + (g.s * j + kx - g.pad)) * ldb)};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.v = r4 < ca ? (uint32_t)((int64_t)kk * g.hb * g.wb * ldb + r4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+
+struct NmWgradSmallR {
+    static constexpr bool KM = false;
+    const float* s1; int64_t ld1; int cb;
+    RectGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ Pos pos(int prob, int chunk) const {
+        int ky, kx, i, j, n0;
+        g.decode(prob, chunk, ky, kx, i, j, n0);
+        return Pos{make_rsrc(s1 + (((int64_t)n0 * g.hs + i) * g.ws + j) * ld1)};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.v = r4 < cb ? (uint32_t)((int64_t)kk * g.hs * g.ws * ld1 + r4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+
+// small side = channels of [s1 | s2]; s2 is the ctx skip shared by both decoder passes (image n % nmod2, nmod2 % 32 == 0)
+struct NmWgradSmall2R {
+    static constexpr bool KM = false;
+    const float* s1; int64_t ld1; int c1;
+    const float* s2; int64_t ld2; int nmod2;
+    int cb;
+    RectGeo g;
+    const float* zeros;
+    struct Pos { rsrc_t r1, r2; };
+    struct Ctx { uint32_t v1, v2; };
+    __device__ Pos pos(int prob, int chunk) const {
+        int ky, kx, i, j, n0;
+        g.decode(prob, chunk, ky, kx, i, j, n0);
+        const int n2 = n0 >= nmod2 ? n0 - nmod2 : n0;
+        return Pos{make_rsrc(s1 + (((int64_t)n0 * g.hs + i) * g.ws + j) * ld1), make_rsrc(s2 + (((int64_t)n2 * g.hs + i) * g.ws + j) * ld2)};
+    }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const {
+        c.v1 = r4 < c1 ? (uint32_t)((int64_t)kk * g.hs * g.ws * ld1 + r4) * 4u : OOB;
+        c.v2 = (r4 >= c1 && r4 < cb) ? (uint32_t)((int64_t)kk * g.hs * g.ws * ld2 + (r4 - c1)) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const {
+        const float4 a = bload4(q.r1, c.v1), b = bload4(q.r2, c.v2);
+        return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+};
+
 // Filter gradient when the big tensor has 3 channels (read from its 4-channel copy): rows m = tap * 4 + ch (100 of 128
 // used), k = output-grid pixel; a lane's float4 is the 4 channels of ONE tap at one pixel.
 struct NmC3WgradBig {

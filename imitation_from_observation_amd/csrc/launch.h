@@ -27,6 +27,9 @@ void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, E
 void conv_wgrad(hipStream_t s, const NmWgradBig& a, const NmWgradSmall& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad2(hipStream_t s, const NmWgradBig& a, const NmWgradSmall2& b, Epi ep, int M, int N, SplitWs ws);
 // power-of-two grids: patch-ordered K (see igemm.h PatchGeo)
+// rectangle-ordered K (nimg % 32 == 0): no SAME-padding zeros are multiplied
+void conv_wgrad_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmallR& b, Epi ep, int M, int N, SplitWs ws);
+void conv_wgrad2_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmall2R& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, Epi ep, int M, int N, SplitWs ws);
 void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws);
 // stride-1 conv2d_transpose as a flipped stride-1 correlation (a.flip = 1, b.flip25 = 1); filter rows as B
