@@ -381,6 +381,9 @@ thread_local const float* g_zeros = nullptr;   // 256 B of device zeros: where t
 NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K, g_zeros}; }
 KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC, g_zeros}; }
 
+// position-major launches (KmConvGatherQ / KmConvTGatherQ) pay once a block is mostly full: rows = images
+bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
+
 // y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
                 const float* b, float* y, int cb) {
@@ -389,6 +392,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
     if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
+    else if (use_q(nimg)) conv_fwd_q(h->stream, KmConvGatherQ{x, ca, make_posgeo(hs, ws, hb, wb, 2, 1, 5, ca / KC), nimg, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ep, cb, ws_of(h));
     else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
 
@@ -514,8 +518,10 @@ void forward(ctx_handle* h, int B, Mode mode) {
             ProfScope ps(h, nm_ + " fwd", K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
-                      KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
+            if (use_q(nd)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
+                                       KmConvTWeightsQ{w, ca, c1 + c2, 5, g_zeros}, ep, ca, ws_of(h));
+            else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
+                           KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
             dec = h->e[k];
         } else {
             const int R = nd * hs * ws;
@@ -579,7 +585,8 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
-              conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
+              if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
+              else conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
         }
         dy = d_dec;
     }
@@ -654,8 +661,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
             ProfScope ps(h, ln + " dx", K_CONVT, fl);
-            convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
-                      ed, R, ca, ws_of(h));
+            if (use_q(nimg)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
+                                         KmConvTWeightsQ{sc.w[k], ca, cb, 5, g_zeros}, ed, ca, ws_of(h));
+            else convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
+                           ed, R, ca, ws_of(h));
         }
     };
     // `conv` on [tgt | src]: code gradients are rows [B, 3B) of dZ; hz_lin has an lrelu

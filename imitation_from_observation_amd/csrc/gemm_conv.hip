@@ -26,6 +26,15 @@ void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, floa
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
+void conv_fwd_q(hipStream_t s, const KmConvGatherQ& a, const NmConvWeightsQ& b, Epi ep, int N, SplitWs ws) {
+    ep.rowmode = 4; ep.hs = a.g.hs; ep.ws = a.g.ws;
+    launch_igemm<KmConvGatherQ, NmConvWeightsQ, true, 1, 0>(s, a, b, ep, a.nimg, N, a.g.hs * a.g.ws, posgeo_min_chunks(a.g), ws);
+}
+void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& b, Epi ep, int N, SplitWs ws) {
+    ep.rowmode = 5; ep.hs = a.g.hs; ep.ws = a.g.ws;
+    const int t = (a.g.K + 1) / 2 - 1;                     // a corner position of the densest class still has this many taps per axis
+    launch_igemm<KmConvTGatherQ, KmConvTWeightsQ, true, 2, 2>(s, a, b, ep, a.nimg, N, 4 * a.g.hs * a.g.ws, (t > 0 ? t * t : 1) * a.g.cps, ws);
+}
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, 4, ws);
 }

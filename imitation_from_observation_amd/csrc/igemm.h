@@ -108,7 +108,8 @@ struct Epi {
     const float* mask = nullptr;    // saved lrelu OUTPUT; v *= (mask >= 0 ? 1 : 0.2) for n < nsplit
     int64_t ldm = 0;
     int lrelu = 0;                  // 1: v = max(v, 0.2 v) after bias/adds; 2: plain ReLU (the Inception front end)
-    int rowmode = 0;                // 0: pix = m; 1: transposed-conv parity class; 2: rows m = tap*4+ch of a C=3 filter gradient
+    int rowmode = 0;                // 0: pix = m; 1: transposed-conv parity class; 2: rows m = tap*4+ch of a C=3 filter gradient;
+                                    // 4 / 5: position-major conv / transposed conv (problem = position, row = image)
     int hs = 0, ws = 0;             // rowmode 1: small-grid size
     int64_t prob_stride = 0;        // out1 += prob * prob_stride (filter gradient: one tap per problem)
     float* slab = nullptr;          // split-K: raw partials to slab[((split*nprob+prob)*M + m)*N + n]
@@ -127,6 +128,17 @@ __device__ __forceinline__ bool epi_row(const Epi& e, int prob, int m, int64_t& 
     if (tap >= 25 || ch == 3) return false;
     pix = tap * 3 + ch;
     return true;
+}
+
+struct RowMap { bool linear; int64_t base, stride; };
+__device__ __forceinline__ RowMap epi_rowmap(const Epi& e, int prob) {
+    if (e.rowmode == 0) return RowMap{true, 0, 1};
+    if (e.rowmode == 4) return RowMap{true, prob, (int64_t)e.hs * e.ws};
+    if (e.rowmode == 5) {
+        const int np = e.hs * e.ws, c = prob / np, pos = prob - c * np, i = pos / e.ws, j = pos - i * e.ws;
+        return RowMap{true, (int64_t)(2 * i + (c >> 1)) * (2 * e.ws) + 2 * j + (c & 1), (int64_t)4 * np};
+    }
+    return RowMap{false, 0, 0};
 }
 
 __device__ __forceinline__ void epi_store(const Epi& e, int prob, int64_t pix, int n, float v) {
@@ -789,6 +801,178 @@ struct NmC3WgradBig {
     }
 };
 
+// ---- position-major convolutions ------------------------------------------------------------------------
+// One PROBLEM per output position; rows m = image index.  Every row of a block then shares the taps that land inside
+// the input grid -- a rectangle [ky0,ky1) x [kx0,kx1) of the kernel -- and K runs over those taps only: the products
+// with SAME-padding zeros (28 % of a 4x4 layer, 14 % of an 8x8 layer) are never formed, no per-lane validity is left in
+// the loop, and a lane's offset is loop-invariant.  The chunk -> (tap, channel slice) decode is done ONCE per chunk
+// (KPos) and shared by both operands.  K order: taps outer, 32-channel slices inner.
+template <class L, class = void> struct has_kpos { static constexpr bool value = false; };
+template <class L> struct has_kpos<L, decltype((void)sizeof(typename L::KPos))> { static constexpr bool value = true; };
+template <class LA, class LB>
+__device__ __forceinline__ void both_pos(const LA& la, const LB& lb, int prob, int c, typename LA::Pos& qa, typename LB::Pos& qb) {
+    if constexpr (has_kpos<LA>::value) {
+        const typename LA::KPos kp = la.kpos(prob, c);
+        qa = la.pos(prob, c, kp);
+        qb = lb.pos(prob, c, kp);
+    } else {
+        qa = la.pos(prob, c);
+        qb = lb.pos(prob, c);
+    }
+}
+struct TapPos { int ky, kx, slice; };          // kernel tap and channel slice of a chunk
+// seg / ntx for seg < 25, 1 <= ntx <= 5
+__device__ __forceinline__ int div_small(int seg, int ntx) {
+    const int m = ntx == 1 ? 256 : ntx == 2 ? 128 : ntx == 3 ? 86 : ntx == 4 ? 64 : 52;
+    return (seg * m) >> 8;
+}
+
+struct PosGeo {
+    int hs, ws, hb, wb, s, pad, K, cps;
+    FastDiv d_ws, d_cps;
+    __device__ __forceinline__ void where(int prob, int& i, int& j) const { i = d_ws.div(prob); j = prob - i * ws; }
+    // taps k in [k0, k0 + nt) with 0 <= s*i + k - pad < nbig
+    __device__ __forceinline__ static void range(int si, int pad, int K, int nbig, int& k0, int& nt) {
+        k0 = pad - si > 0 ? pad - si : 0;
+        const int k1 = nbig + pad - si < K ? nbig + pad - si : K;
+        nt = k1 - k0;
+    }
+    __device__ __forceinline__ int nchunks(int prob) const {
+        int i, j, ky0, nty, kx0, ntx;
+        where(prob, i, j);
+        range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
+        return nty * ntx * cps;
+    }
+    __device__ __forceinline__ TapPos kpos(int prob, int chunk) const {
+        int i, j, ky0, nty, kx0, ntx;
+        where(prob, i, j);
+        range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
+        const int seg = d_cps.div(chunk), r = div_small(seg, ntx);
+        return TapPos{ky0 + r, kx0 + (seg - r * ntx), chunk - seg * cps};
+    }
+};
+inline PosGeo make_posgeo(int hs, int ws, int hb, int wb, int s, int pad, int K, int cps) {
+    return PosGeo{hs, ws, hb, wb, s, pad, K, cps, make_fastdiv(ws), make_fastdiv(cps)};
+}
+inline int posgeo_min_chunks(const PosGeo& g) {                  // the corner position
+    auto nt = [&](int si, int nbig) { int k0 = g.pad - si > 0 ? g.pad - si : 0, k1 = nbig + g.pad - si < g.K ? nbig + g.pad - si : g.K; return k1 - k0; };
+    int best = 1 << 30;
+    for (int i : {0, g.hs - 1})
+        for (int j : {0, g.ws - 1}) { const int n = nt(g.s * i, g.hb) * nt(g.s * j, g.wb) * g.cps; if (n < best) best = n; }
+    return best;
+}
+
+// conv2d operand: problem = output position (i,j), row = image.  Epilogue rowmode 4.
+struct KmConvGatherQ {
+    static constexpr bool KM = true;
+    const float* x; int64_t ldx;
+    PosGeo g;
+    int nimg;
+    const float* zeros;
+    typedef TapPos KPos;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
+    __device__ KPos kpos(int prob, int chunk) const { return g.kpos(prob, chunk); }
+    __device__ Pos pos(int, int, const KPos& t) const {
+        return Pos{make_rsrc(x + ((int64_t)(t.ky - g.pad) * g.wb + (t.kx - g.pad)) * ldx + t.slice * KC)};
+    }
+    __device__ void prep(int prob, int row, int k4, Ctx& c) const {
+        int i, j;
+        g.where(prob, i, j);
+        c.v = row < nimg ? (uint32_t)((((int64_t)row * g.hb + g.s * i) * g.wb + g.s * j) * ldx + k4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+// its filter [K][K][cin][cout] as the B operand (rows = cout)
+struct NmConvWeightsQ {
+    static constexpr bool KM = false;
+    const float* w; int cin, cout, K;
+    const float* zeros;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ Pos pos(int, int, const TapPos& t) const { return Pos{make_rsrc(w + ((int64_t)(t.ky * K + t.kx) * cin + t.slice * KC) * cout)}; }
+    __device__ void prep(int, int kk, int r4, Ctx& c) const { c.v = r4 < cout ? (uint32_t)(kk * cout + r4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+
+// conv2d_transpose, stride 2: problem = class * (hs*ws) + input-grid position (i',j') (class = output parity (py,px));
+// row = image; valid taps sy in [sy0, sy1) with 0 <= i' + oy - sy < hs (KmConvTGather's notation).  Epilogue rowmode 5.
+struct TPosGeo {
+    int hs, ws, K, pb, cps;
+    FastDiv d_np, d_ws, d_cps;
+    struct Where { int py, px, i, j, oy, ox, sy0, nty, sx0, ntx, pary, parx; };
+    __device__ __forceinline__ static void cls(int p, int pb, int K, int& par, int& nt, int& off) {
+        par = (p + pb) & 1; nt = (K - par + 1) >> 1; off = (p + pb - par) >> 1;
+    }
+    __device__ __forceinline__ Where where(int prob) const {
+        Where w;
+        const int c = d_np.div(prob), pos = prob - c * hs * ws;
+        w.py = c >> 1; w.px = c & 1;
+        w.i = d_ws.div(pos); w.j = pos - w.i * ws;
+        int nty, ntx;
+        cls(w.py, pb, K, w.pary, nty, w.oy); cls(w.px, pb, K, w.parx, ntx, w.ox);
+        // 0 <= i + oy - sy < hs  <=>  i + oy - hs < sy <= i + oy
+        w.sy0 = w.i + w.oy - hs + 1 > 0 ? w.i + w.oy - hs + 1 : 0;
+        const int sy1 = w.i + w.oy + 1 < nty ? w.i + w.oy + 1 : nty;
+        w.nty = sy1 - w.sy0;
+        w.sx0 = w.j + w.ox - ws + 1 > 0 ? w.j + w.ox - ws + 1 : 0;
+        const int sx1 = w.j + w.ox + 1 < ntx ? w.j + w.ox + 1 : ntx;
+        w.ntx = sx1 - w.sx0;
+        return w;
+    }
+    struct KPos { int sy, sx, slice, oy, ox, pary, parx; };
+    __device__ __forceinline__ int nchunks(int prob) const { const Where w = where(prob); return w.nty * w.ntx * cps; }
+    __device__ __forceinline__ KPos kpos(int prob, int chunk) const {
+        const Where w = where(prob);
+        const int seg = d_cps.div(chunk), r = div_small(seg, w.ntx);
+        return KPos{w.sy0 + r, w.sx0 + (seg - r * w.ntx), chunk - seg * cps, w.oy, w.ox, w.pary, w.parx};
+    }
+};
+inline TPosGeo make_tposgeo(int hs, int ws, int K, int pb, int cps) {
+    return TPosGeo{hs, ws, K, pb, cps, make_fastdiv(hs * ws), make_fastdiv(ws), make_fastdiv(cps)};
+}
+struct KmConvTGatherQ {
+    static constexpr bool KM = true;
+    const float* s1; int64_t ld1; int c1;   // c1 a multiple of KC
+    const float* s2; int64_t ld2; int nmod2;
+    TPosGeo g;
+    int nimg;
+    const float* zeros;
+    typedef TPosGeo::KPos KPos;
+    struct Pos { rsrc_t rs; bool second; };
+    struct Ctx { uint32_t v1, v2; };
+    __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
+    __device__ KPos kpos(int prob, int chunk) const { return g.kpos(prob, chunk); }
+    __device__ Pos pos(int, int, const KPos& t) const {
+        const int64_t d = (int64_t)(t.oy - t.sy) * g.ws + (t.ox - t.sx);
+        const int kc = t.slice * KC;
+        const bool second = kc >= c1;
+        return Pos{make_rsrc(second ? s2 + d * ld2 + (kc - c1) : s1 + d * ld1 + kc), second};
+    }
+    __device__ void prep(int prob, int row, int k4, Ctx& c) const {
+        const TPosGeo::Where w = g.where(prob);
+        const int64_t pix = (int64_t)w.i * g.ws + w.j, hw = (int64_t)g.hs * g.ws;
+        c.v1 = row < nimg ? (uint32_t)((row * hw + pix) * ld1 + k4) * 4u : OOB;
+        c.v2 = row < nimg ? (uint32_t)(((row % nmod2) * hw + pix) * ld2 + k4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v2 : c.v1); }
+};
+// its filter w[ky][kx][a][b] (a = output channel = tile row, b = k) as the B operand
+struct KmConvTWeightsQ {
+    static constexpr bool KM = true;
+    const float* w; int ca, cb, K;
+    const float* zeros;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ Pos pos(int, int, const TPosGeo::KPos& t) const {
+        const int ky = t.pary + 2 * t.sy, kx = t.parx + 2 * t.sx;
+        return Pos{make_rsrc(w + (int64_t)(ky * K + kx) * ca * cb + t.slice * KC)};
+    }
+    __device__ void prep(int, int row, int k4, Ctx& c) const { c.v = row < ca ? (uint32_t)(row * cb + k4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+
 // ------------------------------------------------------------------------------------------------
 // LDS tiles.  NT = threads of the block that cooperate on a tile.
 // ------------------------------------------------------------------------------------------------
@@ -894,8 +1078,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
         float4 xa[NA], xb[NB], ya[TWO_SETS ? NA : 1], yb[TWO_SETS ? NB : 1];
         // prologue: chunk cb -> stage 0 ; chunk cb+1 -> set X
         {
-            const typename LA::Pos qa = la.pos(prob, cb);
-            const typename LB::Pos qb = lb.pos(prob, cb);
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, cb, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -906,8 +1091,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
 #pragma unroll
         for (int p = 0; p < NB; ++p) TB::store(smem + TA::FLOATS, tid, p, xb[p]);
         {
-            const typename LA::Pos qa = la.pos(prob, clampc(cb + 1));
-            const typename LB::Pos qb = lb.pos(prob, clampc(cb + 1));
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, clampc(cb + 1), qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -924,8 +1110,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
             float* nA = smem + (st ^ 1) * STAGE;
             float* nB = nA + TA::FLOATS;
             // where chunk c+2 lives: wave-uniform, once per chunk, on the scalar unit
-            const typename LA::Pos qa = la.pos(prob, clampc(c + 2));
-            const typename LB::Pos qb = lb.pos(prob, clampc(c + 2));
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, clampc(c + 2), qa, qb);
             float a[2][MI][4], b[2][NI][4];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) TA::frag(sA, (wm * MI + mi) * 32 + l31, 0, h, a[0][mi]);
@@ -974,6 +1161,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     }
 
     // D layout (32x32 MFMA): col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // position-major launches (rowmode 4 / 5): the destination pixel is LINEAR in the row (= image) index; the
+    // block-uniform part is resolved once here, outside the unrolled loops
+    const RowMap rmap = epi_rowmap(ep, prob);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -988,7 +1178,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
                 }
             } else {
                 int64_t pix;
-                if (!epi_row(ep, prob, m, pix)) continue;
+                if (rmap.linear) pix = rmap.base + (int64_t)m * rmap.stride;
+                else if (!epi_row(ep, prob, m, pix)) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = n0 + (wn * NI + ni) * 32 + l31;

@@ -150,8 +150,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
         auto clampc = [&](int c) { return c < last ? c : last; };
         float4 xa[NA], xb[NB], ya[TWO_SETS ? NA : 1], yb[TWO_SETS ? NB : 1];
         {
-            const typename LA::Pos qa = la.pos(prob, cb);
-            const typename LB::Pos qb = lb.pos(prob, cb);
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, cb, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -162,8 +163,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
 #pragma unroll
         for (int p = 0; p < NB; ++p) TB::store(smem_u + TA::FLOATS, tid, p, xb);
         {
-            const typename LA::Pos qa = la.pos(prob, clampc(cb + 1));
-            const typename LB::Pos qb = lb.pos(prob, clampc(cb + 1));
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, clampc(cb + 1), qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -180,8 +182,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
             const uint32_t* sB = sA + TA::FLOATS;
             uint32_t* nA = smem_u + (st ^ 1) * STAGE;
             uint32_t* nB = nA + TA::FLOATS;
-            const typename LA::Pos qa = la.pos(prob, clampc(c + 2));
-            const typename LB::Pos qb = lb.pos(prob, clampc(c + 2));
+            typename LA::Pos qa;
+            typename LB::Pos qb;
+            both_pos(la, lb, prob, clampc(c + 2), qa, qb);
             u32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -226,6 +229,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
         }
     }
 
+    // position-major launches (rowmode 4 / 5): the destination pixel is LINEAR in the row (= image) index; the
+    // block-uniform part is resolved once here, outside the unrolled loops
+    const RowMap rmap = epi_rowmap(ep, prob);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -240,7 +246,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
                 }
             } else {
                 int64_t pix;
-                if (!epi_row(ep, prob, m, pix)) continue;
+                if (rmap.linear) pix = rmap.base + (int64_t)m * rmap.stride;
+                else if (!epi_row(ep, prob, m, pix)) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = n0 + (wn * NI + ni) * 32 + l31;

@@ -17,7 +17,9 @@ __global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const Epi ep, i
         float v = 0.f;
         for (int s = 0; s < nsplit; ++s) v += ep.slab[(int64_t)s * total + idx];
         int64_t pix;
-        if (epi_row(ep, prob, m, pix)) epi_store(ep, prob, pix, n, v);
+        const RowMap rm = epi_rowmap(ep, prob);
+        if (rm.linear) epi_store(ep, prob, rm.base + (int64_t)m * rm.stride, n, v);
+        else if (epi_row(ep, prob, m, pix)) epi_store(ep, prob, pix, n, v);
     }
 }
 

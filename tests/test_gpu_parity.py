@@ -84,6 +84,29 @@ def test_forward_backward_matches_oracle(T, H, W, d, F, B):
         np.testing.assert_array_equal(tr.get_params_flat(), o.flatten(p, cfg, np.float32))   # lr 0 => unchanged
 
 
+@pytest.mark.parametrize("H,W,d,F,B", [(16, 16, 32, 32, 64), (32, 16, 32, 64, 32), (16, 32, 32, 32, 96)])
+def test_position_major_launches_match_oracle(T, H, W, d, F, B):
+    """Batches of >= 64 images per launch take the position-major conv / transposed-conv kernels (one problem per output
+    position, only the taps inside the grid) and the rectangle-ordered filter gradient: same parity bar."""
+    cfg, p, fr = make_case(H, W, d, F, B, seed=7)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    from tests._align import align_skipnew_cache
+    res, c = o.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    with T(H, W, d, F, max_batch=B) as tr:
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        assert relmax(ev["out"], res["out"]) < 1e-5 and relmax(ev["out2"], res["out2"]) < 1e-5
+        # activations within fp32 rounding of zero take the device's lrelu' branch in the oracle too (tests/_align.py)
+        nflip, worst = align_skipnew_cache(tr, c, B)
+        assert worst < 1e-5
+        g = o.backward(p, c, cfg)
+        sc = tr.train_step(src, ctx, tgt, lr=0.0)
+        assert abs(sc["loss"] - res["loss"]) <= 1e-5 * abs(res["loss"])
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-4, (n, nflip)
+
+
 @pytest.mark.parametrize("steps", [3])
 def test_adam_trajectory_matches_oracle(T, steps):
     H, W, d, F, B = 32, 32, 32, 128, 4
