@@ -382,7 +382,10 @@ NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nul
 KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC, g_zeros}; }
 
 // position-major launches (KmConvGatherQ / KmConvTGatherQ) pay once a block is mostly full: rows = images
+// (transposed conv on 4x4 grids: 64 problems of 1..9 taps leave a long tail; the class-major launch stays faster there)
 bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
+
+int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = getenv("CTX_Q_MINPOS"); return e ? atoi(e) : -1; }(); return v >= 0 ? v : (h->cfg.precision ? 0 : 64); }
 
 // y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
@@ -518,7 +521,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
             ProfScope ps(h, nm_ + " fwd", K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            if (use_q(nd)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
+            if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
                                        KmConvTWeightsQ{w, ca, c1 + c2, 5, g_zeros}, ep, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
                            KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
@@ -661,7 +664,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
             ProfScope ps(h, ln + " dx", K_CONVT, fl);
-            if (use_q(nimg)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
+            if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
                                          KmConvTWeightsQ{sc.w[k], ca, cb, 5, g_zeros}, ed, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
                            ed, R, ca, ws_of(h));

@@ -809,10 +809,16 @@ struct NmC3WgradBig {
 // (KPos) and shared by both operands.  K order: taps outer, 32-channel slices inner.
 template <class L, class = void> struct has_kpos { static constexpr bool value = false; };
 template <class L> struct has_kpos<L, decltype((void)sizeof(typename L::KPos))> { static constexpr bool value = true; };
-template <class LA, class LB>
-__device__ __forceinline__ void both_pos(const LA& la, const LB& lb, int prob, int c, typename LA::Pos& qa, typename LB::Pos& qb) {
+struct NoKBlock {};
+template <class LA>
+__device__ __forceinline__ auto make_kblock(const LA& la, int prob) {      // the block-invariant part of the decode (taps of this position)
+    if constexpr (has_kpos<LA>::value) return la.kblock(prob);
+    else return NoKBlock{};
+}
+template <class LA, class LB, class KB>
+__device__ __forceinline__ void both_pos(const LA& la, const LB& lb, int prob, int c, const KB& kb, typename LA::Pos& qa, typename LB::Pos& qb) {
     if constexpr (has_kpos<LA>::value) {
-        const typename LA::KPos kp = la.kpos(prob, c);
+        const typename LA::KPos kp = la.kpos(kb, c);
         qa = la.pos(prob, c, kp);
         qb = lb.pos(prob, c, kp);
     } else {
@@ -843,12 +849,16 @@ struct PosGeo {
         range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
         return nty * ntx * cps;
     }
-    __device__ __forceinline__ TapPos kpos(int prob, int chunk) const {
+    struct Blk { int ky0, kx0, ntx; };
+    __device__ __forceinline__ Blk kblock(int prob) const {
         int i, j, ky0, nty, kx0, ntx;
         where(prob, i, j);
         range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
-        const int seg = d_cps.div(chunk), r = div_small(seg, ntx);
-        return TapPos{ky0 + r, kx0 + (seg - r * ntx), chunk - seg * cps};
+        return Blk{ky0, kx0, ntx};
+    }
+    __device__ __forceinline__ TapPos kpos(const Blk& b, int chunk) const {
+        const int seg = d_cps.div(chunk), r = div_small(seg, b.ntx);
+        return TapPos{b.ky0 + r, b.kx0 + (seg - r * b.ntx), chunk - seg * cps};
     }
 };
 inline PosGeo make_posgeo(int hs, int ws, int hb, int wb, int s, int pad, int K, int cps) {
@@ -870,10 +880,12 @@ struct KmConvGatherQ {
     int nimg;
     const float* zeros;
     typedef TapPos KPos;
+    typedef PosGeo::Blk KBlock;
     struct Pos { rsrc_t rs; };
     struct Ctx { uint32_t v; };
     __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
-    __device__ KPos kpos(int prob, int chunk) const { return g.kpos(prob, chunk); }
+    __device__ KBlock kblock(int prob) const { return g.kblock(prob); }
+    __device__ KPos kpos(const KBlock& b, int chunk) const { return g.kpos(b, chunk); }
     __device__ Pos pos(int, int, const KPos& t) const {
         return Pos{make_rsrc(x + ((int64_t)(t.ky - g.pad) * g.wb + (t.kx - g.pad)) * ldx + t.slice * KC)};
     }
@@ -923,10 +935,14 @@ struct TPosGeo {
     }
     struct KPos { int sy, sx, slice, oy, ox, pary, parx; };
     __device__ __forceinline__ int nchunks(int prob) const { const Where w = where(prob); return w.nty * w.ntx * cps; }
-    __device__ __forceinline__ KPos kpos(int prob, int chunk) const {
+    struct Blk { int sy0, sx0, ntx, oy, ox, pary, parx; };
+    __device__ __forceinline__ Blk kblock(int prob) const {
         const Where w = where(prob);
-        const int seg = d_cps.div(chunk), r = div_small(seg, w.ntx);
-        return KPos{w.sy0 + r, w.sx0 + (seg - r * w.ntx), chunk - seg * cps, w.oy, w.ox, w.pary, w.parx};
+        return Blk{w.sy0, w.sx0, w.ntx, w.oy, w.ox, w.pary, w.parx};
+    }
+    __device__ __forceinline__ KPos kpos(const Blk& b, int chunk) const {
+        const int seg = d_cps.div(chunk), r = div_small(seg, b.ntx);
+        return KPos{b.sy0 + r, b.sx0 + (seg - r * b.ntx), chunk - seg * cps, b.oy, b.ox, b.pary, b.parx};
     }
 };
 inline TPosGeo make_tposgeo(int hs, int ws, int K, int pb, int cps) {
@@ -940,10 +956,12 @@ struct KmConvTGatherQ {
     int nimg;
     const float* zeros;
     typedef TPosGeo::KPos KPos;
+    typedef TPosGeo::Blk KBlock;
     struct Pos { rsrc_t rs; bool second; };
     struct Ctx { uint32_t v1, v2; };
     __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
-    __device__ KPos kpos(int prob, int chunk) const { return g.kpos(prob, chunk); }
+    __device__ KBlock kblock(int prob) const { return g.kblock(prob); }
+    __device__ KPos kpos(const KBlock& b, int chunk) const { return g.kpos(b, chunk); }
     __device__ Pos pos(int, int, const KPos& t) const {
         const int64_t d = (int64_t)(t.oy - t.sy) * g.ws + (t.ox - t.sx);
         const int kc = t.slice * KC;
@@ -1054,6 +1072,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     const int split = rest / nprob;
     const int m0 = bx * TM, n0 = by * TN;
 
+    const auto kblk = make_kblock(la, prob);
     const int nch = la.nchunks_of(prob);
     const int per = (nch + nsplit - 1) / nsplit;
     const int cb = split * per;
@@ -1080,7 +1099,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
         {
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, cb, qa, qb);
+            both_pos(la, lb, prob, cb, kblk, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -1093,7 +1112,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
         {
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, clampc(cb + 1), qa, qb);
+            both_pos(la, lb, prob, clampc(cb + 1), kblk, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
             // where chunk c+2 lives: wave-uniform, once per chunk, on the scalar unit
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, clampc(c + 2), qa, qb);
+            both_pos(la, lb, prob, clampc(c + 2), kblk, qa, qb);
             float a[2][MI][4], b[2][NI][4];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) TA::frag(sA, (wm * MI + mi) * 32 + l31, 0, h, a[0][mi]);

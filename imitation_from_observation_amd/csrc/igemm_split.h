@@ -127,6 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
     const int split = rest / nprob;
     const int m0 = bx * TM, n0 = by * TN;
 
+    const auto kblk = make_kblock(la, prob);
     const int nch = la.nchunks_of(prob);
     const int per = (nch + nsplit - 1) / nsplit;
     const int cb = split * per;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
         {
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, cb, qa, qb);
+            both_pos(la, lb, prob, cb, kblk, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
         {
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, clampc(cb + 1), qa, qb);
+            both_pos(la, lb, prob, clampc(cb + 1), kblk, qa, qb);
 #pragma unroll
             for (int p = 0; p < NA; ++p) xa[p] = fa.load1(la, qa, p);
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
             uint32_t* nB = nA + TA::FLOATS;
             typename LA::Pos qa;
             typename LB::Pos qb;
-            both_pos(la, lb, prob, clampc(c + 2), qa, qb);
+            both_pos(la, lb, prob, clampc(c + 2), kblk, qa, qb);
             u32x4 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
