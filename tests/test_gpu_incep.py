@@ -89,3 +89,21 @@ def test_incep2_adam_and_split_precision(T):
         assert abs(l0 - res["loss"]) <= 1e-5 * res["loss"] and l1 < l0
         evb = b.evaluate(src, ctx, tgt)
         assert relmax(evb["out"], res["out"]) < 2e-4 and abs(evb["loss"] - res["loss"]) <= 2e-4 * res["loss"]
+
+
+@pytest.mark.parametrize("H,W,C,d,F,B", [(2, 2, 64, 4, 64, 64), (4, 4, 32, 4, 32, 32)])
+def test_incep2_position_major_batches(T, H, W, C, d, F, B):
+    """>= 64 images per launch: the position-major / rectangle-ordered kernels (on a 2x2 grid 4 of the 9 taps of a 3x3
+    kernel see data, on the 1x1 grids one of 9 -- the rest is never multiplied)."""
+    cfg, p, (src, ctx, tgt) = make(H, W, C, d, F, B, seed=4)
+    res, c = oi.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = oi.backward(p, c, cfg)
+    with T(H, W, df_dim=d, featsize=F, max_batch=B, variant="inception2", C=C) as tr:
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        assert relmax(ev["out"], res["out"]) < 1e-5 and abs(ev["loss"] - res["loss"]) <= 1e-5 * res["loss"]
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-3, n            # lrelu' flips at fp32 zero are not aligned here (B*h*w*C activations)
+            assert np.linalg.norm(np.asarray(gg[n], np.float64) - g[n]) <= 2e-3 * np.linalg.norm(g[n]), n

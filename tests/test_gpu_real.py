@@ -134,3 +134,21 @@ def test_real_golden_vectors(T):
                     h = min(64, a.size)
                     assert np.abs(a[:h] - z["grad_head"][i][:h]).max() <= 1e-4 * np.abs(a).max() + 1e-12, n
             np.testing.assert_allclose(sc["loss"], z["train_scalars"][t][0], rtol=2e-5)
+
+
+def test_real_position_major_batches(T):
+    """3B = 96 images per encoder launch, 2B = 64 per decoder launch: position-major / rectangle-ordered kernels."""
+    H, W, B = 12, 16, 32
+    cfg, p, fr = make(H, W, B, seed=6)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    res, c = r.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = r.backward(p, c, cfg)
+    with T(H, W, featsize=100, max_batch=B, variant="real") as tr:
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        assert relmax(ev["out"], res["out"]) < 1e-5 and abs(ev["loss"] - res["loss"]) <= 1e-5 * res["loss"]
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-3, n
+            assert np.linalg.norm(np.asarray(gg[n], np.float64) - g[n]) <= 2e-3 * np.linalg.norm(g[n]), n
