@@ -108,14 +108,20 @@ int run(ctx_cnn* h, int n) {
         if (op.kind == CTX_CNN_MAXPOOL) { maxpool3x3s2(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
         if (op.kind == CTX_CNN_AVGPOOL) { avgpool3x3s1(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
         const int R = n * out.h * out.w;
-        KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
-        a.s = op.stride; a.K = op.kh; a.KW = op.kw;
-        a.pad = op.same ? same_before(in.h, op.kh, op.stride) : 0;
-        a.padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
         const float* w = h->weights + op.w_off;
-        NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
         Epi ep;
         ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
+        const int pady = op.same ? same_before(in.h, op.kh, op.stride) : 0, padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
+        if (n >= 64 && op.same && op.kh * op.kw > 1) {       // position-major: SAME-padding taps outside the grid are never multiplied
+            PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, in.c / KC);
+            g.KW = op.kw; g.padx = padx;
+            conv_fwd_q(h->stream, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, in.c, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
+            continue;
+        }
+        KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
+        a.s = op.stride; a.K = op.kh; a.KW = op.kw;
+        a.pad = pady; a.padx = padx;
+        NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
         conv_fwd(h->stream, a, b, ep, R, op.cout, ws);
     }
     if (hipGetLastError() != hipSuccess) return cfail(h, CTX_E_DEVICE, "kernel launch failed");

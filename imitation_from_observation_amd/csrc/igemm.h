@@ -827,15 +827,18 @@ __device__ __forceinline__ void both_pos(const LA& la, const LB& lb, int prob, i
     }
 }
 struct TapPos { int ky, kx, slice; };          // kernel tap and channel slice of a chunk
-// seg / ntx for seg < 25, 1 <= ntx <= 5
+// seg / ntx for seg < 25, 1 <= ntx <= 7
 __device__ __forceinline__ int div_small(int seg, int ntx) {
-    const int m = ntx == 1 ? 256 : ntx == 2 ? 128 : ntx == 3 ? 86 : ntx == 4 ? 64 : 52;
+    const int m = ntx == 1 ? 256 : ntx == 2 ? 128 : ntx == 3 ? 86 : ntx == 4 ? 64 : ntx == 5 ? 52 : ntx == 6 ? 43 : 37;
     return (seg * m) >> 8;
 }
 
 struct PosGeo {
     int hs, ws, hb, wb, s, pad, K, cps;
     FastDiv d_ws, d_cps;
+    int KW = 0, padx = -1;           // kernel width / left pad when they differ from K / pad (Inception's 1x7, 7x1, 1x3, 3x1)
+    __host__ __device__ int kw() const { return KW ? KW : K; }
+    __host__ __device__ int px() const { return padx >= 0 ? padx : pad; }
     __device__ __forceinline__ void where(int prob, int& i, int& j) const { i = d_ws.div(prob); j = prob - i * ws; }
     // taps k in [k0, k0 + nt) with 0 <= s*i + k - pad < nbig
     __device__ __forceinline__ static void range(int si, int pad, int K, int nbig, int& k0, int& nt) {
@@ -846,14 +849,14 @@ struct PosGeo {
     __device__ __forceinline__ int nchunks(int prob) const {
         int i, j, ky0, nty, kx0, ntx;
         where(prob, i, j);
-        range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
+        range(s * i, pad, K, hb, ky0, nty); range(s * j, px(), kw(), wb, kx0, ntx);
         return nty * ntx * cps;
     }
     struct Blk { int ky0, kx0, ntx; };
     __device__ __forceinline__ Blk kblock(int prob) const {
         int i, j, ky0, nty, kx0, ntx;
         where(prob, i, j);
-        range(s * i, pad, K, hb, ky0, nty); range(s * j, pad, K, wb, kx0, ntx);
+        range(s * i, pad, K, hb, ky0, nty); range(s * j, px(), kw(), wb, kx0, ntx);
         return Blk{ky0, kx0, ntx};
     }
     __device__ __forceinline__ TapPos kpos(const Blk& b, int chunk) const {
@@ -865,10 +868,10 @@ inline PosGeo make_posgeo(int hs, int ws, int hb, int wb, int s, int pad, int K,
     return PosGeo{hs, ws, hb, wb, s, pad, K, cps, make_fastdiv(ws), make_fastdiv(cps)};
 }
 inline int posgeo_min_chunks(const PosGeo& g) {                  // the corner position
-    auto nt = [&](int si, int nbig) { int k0 = g.pad - si > 0 ? g.pad - si : 0, k1 = nbig + g.pad - si < g.K ? nbig + g.pad - si : g.K; return k1 - k0; };
+    auto nt = [&](int si, int nbig, int pad, int K) { int k0 = pad - si > 0 ? pad - si : 0, k1 = nbig + pad - si < K ? nbig + pad - si : K; return k1 - k0; };
     int best = 1 << 30;
     for (int i : {0, g.hs - 1})
-        for (int j : {0, g.ws - 1}) { const int n = nt(g.s * i, g.hb) * nt(g.s * j, g.wb) * g.cps; if (n < best) best = n; }
+        for (int j : {0, g.ws - 1}) { const int n = nt(g.s * i, g.hb, g.pad, g.K) * nt(g.s * j, g.wb, g.px(), g.kw()) * g.cps; if (n < best) best = n; }
     return best;
 }
 
@@ -887,7 +890,7 @@ struct KmConvGatherQ {
     __device__ KBlock kblock(int prob) const { return g.kblock(prob); }
     __device__ KPos kpos(const KBlock& b, int chunk) const { return g.kpos(b, chunk); }
     __device__ Pos pos(int, int, const KPos& t) const {
-        return Pos{make_rsrc(x + ((int64_t)(t.ky - g.pad) * g.wb + (t.kx - g.pad)) * ldx + t.slice * KC)};
+        return Pos{make_rsrc(x + ((int64_t)(t.ky - g.pad) * g.wb + (t.kx - g.px())) * ldx + t.slice * KC)};
     }
     __device__ void prep(int prob, int row, int k4, Ctx& c) const {
         int i, j;
@@ -899,7 +902,7 @@ struct KmConvGatherQ {
 // its filter [K][K][cin][cout] as the B operand (rows = cout)
 struct NmConvWeightsQ {
     static constexpr bool KM = false;
-    const float* w; int cin, cout, K;
+    const float* w; int cin, cout, K;     // K = kernel WIDTH (row index = ky * K + kx)
     const float* zeros;
     struct Pos { rsrc_t rs; };
     struct Ctx { uint32_t v; };

@@ -89,6 +89,25 @@ def test_chunking_device_entry_and_padding_stay_clean(front):
 
 
 @pytest.mark.gpu
+def test_position_major_batch_matches_per_image_pass():
+    """>= 64 images per pass take the position-major conv for the SAME-padded layers (taps outside the grid are skipped:
+    on the 2x2 grid of Mixed_7 that is 5 of the 9 taps of a 3x3 kernel): same features as the small-batch path, and the oracle's."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd.inception_frontend import InceptionFrontend
+    from oracle.ctx_oracle import preprocess_u8
+    u8 = np.random.default_rng(5).integers(0, 256, (66, 125, 125, 3), dtype=np.uint8)
+    with InceptionFrontend(125, 125, max_images=66) as big, InceptionFrontend(125, 125, max_images=2) as small:
+        tree = big.init_synthetic(7)
+        small.set_variables(tree)
+        fb, fs = big.features(u8), small.features(u8)
+        assert relmax(fb, fs) < 1e-5
+        ref = io.forward({k: v.astype(np.float64) for k, v in tree.items()}, preprocess_u8(u8[:2]).astype(np.float64))["Mixed_7c"]
+        assert relmax(fb[:2], ref) < 1e-4
+
+
+@pytest.mark.gpu
 def test_split_precision_front_end():
     import torch
     if not torch.cuda.is_available():
