@@ -2,6 +2,7 @@
 // The same two kernels also compute each other's input gradient.
 #include "gemm_launch.h"
 namespace ctx {
+int xcd_swz() { static const int v = [] { const char* e = getenv("CTX_XCD_SWIZZLE"); return e ? atoi(e) : 0; }(); return v; }
 void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, int M, int N, SplitWs ws) {
     NmPlain b = b_;
     b.seglen = a.tap_outer ? 0 : a.cps * KC;     // filter rows in KmConvGather's K order (A/B measured: no difference)
@@ -27,11 +28,11 @@ void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, E
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
 void conv_fwd_q(hipStream_t s, const KmConvGatherQ& a, const NmConvWeightsQ& b, Epi ep, int N, SplitWs ws) {
-    ep.rowmode = 4; ep.hs = a.g.hs; ep.ws = a.g.ws;
+    ep.rowmode = 4; ep.hs = a.g.hs; ep.ws = a.g.ws; ep.xcd_swizzle = xcd_swz();
     launch_igemm<KmConvGatherQ, NmConvWeightsQ, true, 1, 0>(s, a, b, ep, a.nimg, N, a.g.hs * a.g.ws, posgeo_min_chunks(a.g), ws);
 }
 void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& b, Epi ep, int N, SplitWs ws) {
-    ep.rowmode = 5; ep.hs = a.g.hs; ep.ws = a.g.ws;
+    ep.rowmode = 5; ep.hs = a.g.hs; ep.ws = a.g.ws; ep.xcd_swizzle = xcd_swz();
     const int t = (a.g.K + 1) / 2 - 1;                     // a corner position of the densest class still has this many taps per axis
     launch_igemm<KmConvTGatherQ, KmConvTWeightsQ, true, 2, 2>(s, a, b, ep, a.nimg, N, 4 * a.g.hs * a.g.ws, (t > 0 ? t * t : 1) * a.g.cps, ws);
 }

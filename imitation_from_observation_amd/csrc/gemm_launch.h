@@ -20,7 +20,9 @@ static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, const Epi
         raised = true;
     }
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
-    dim3 grid((unsigned)((int64_t)gm * gn * nprob * nsplit));
+    int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
+    if (ep.xcd_swizzle) nblk = (nblk + 7) / 8 * 8;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL((igemm_split_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 
@@ -35,7 +37,9 @@ static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, const Epi& 
         raised = true;
     }
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
-    dim3 grid((unsigned)((int64_t)gm * gn * nprob * nsplit));
+    int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
+    if (ep.xcd_swizzle) nblk = (nblk + 7) / 8 * 8;
+    dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 

@@ -113,6 +113,7 @@ struct Epi {
     int hs = 0, ws = 0;             // rowmode 1: small-grid size
     int64_t prob_stride = 0;        // out1 += prob * prob_stride (filter gradient: one tap per problem)
     float* slab = nullptr;          // split-K: raw partials to slab[((split*nprob+prob)*M + m)*N + n]
+    int xcd_swizzle = 0;            // 1: consecutive work items go to the SAME XCD (its L2): block b does item (b % 8) * ceil(T/8) + b / 8
 };
 
 // returns false if the row has no destination
@@ -1066,6 +1067,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     // (1,1) parity class of a transposed conv has 9 taps against 4 for (0,0), and the longest blocks
     // must not form the tail.  (XCD-contiguous and n-tile-fastest orders were measured: -8..-20 %.)
     int rest = blockIdx.x;
+    if (ep.xcd_swizzle) {                               // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of work
+        const int per = (int)gridDim.x >> 3, item = (rest & 7) * per + (rest >> 3);   // the launcher pads the grid to a multiple of 8
+        if (item >= gm * gn * nprob * nsplit) return;
+        rest = item;
+    }
     const int bx = rest % gm; rest /= gm;
     const int by = rest % gn; rest /= gn;
     // transposed conv (nprob == 4): parity classes have 4/6/6/9 taps.  Dispatching 9,6,4,6 makes the two

@@ -119,7 +119,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wm = wv / WN, wn = wv % WN, l31 = lane & 31, h = lane >> 5;
 
-    int rest = blockIdx.x;                              // same block order as igemm_kernel
+    int rest = blockIdx.x;
+    if (ep.xcd_swizzle) {                               // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of work
+        const int per = (int)gridDim.x >> 3, item = (rest & 7) * per + (rest >> 3);   // the launcher pads the grid to a multiple of 8
+        if (item >= gm * gn * nprob * nsplit) return;
+        rest = item;
+    }                              // same block order as igemm_kernel
     const int bx = rest % gm; rest /= gm;
     const int by = rest % gn; rest /= gn;
     const int pr = rest % nprob;
