@@ -12,19 +12,22 @@
 // Nothing is materialised in HBM: each block gathers 128-B channel runs of the pixels it needs
 // straight into LDS (coalesced), and the 25-tap reuse comes from L2.
 //
-// Block = 256 threads = 4 waves (2 x 2), block tile (64*MI) x (64*NI), K staged KC = 32 at a time
-// through a double-buffered LDS ring with ONE barrier per chunk.  Measured anatomy on MI355X
-// (tools/mfma_ablate.hip): the MFMA stream alone runs at the 152 TF/s pipe peak (2.32 GHz); what
-// costs is anything that sits BETWEEN a barrier and the first MFMA.  Therefore
-//   * loaders are branch-free -- out-of-range lanes (SAME padding, ragged edges) read a zero page, so
-//     the whole chunk body is one basic block the scheduler can interleave;
-//   * per-row state (base pointer, 25-bit tap-validity mask) is hoisted out of the K loop; per chunk
-//     only a wave-uniform offset is added;
-//   * the global loads of chunk c+2 and the LDS stores of chunk c+1 are issued in the gaps between
-//     the MFMA groups of chunk c (two register sets: 1.5 chunks between a load and its first use).
-// What did NOT help (measured, kept out): XCD-contiguous / n-tile-fastest block orders (-8..-20 %),
-// pinning the schedule with sched_barrier (-2 %).  What remains (72 % of the pipe peak at the measured
-// clock) tracks L2-miss traffic per FLOP, not latency: see DESIGN.md section 6.
+// Block = WM x WN waves, block tile (32*MI*WM) x (32*NI*WN), K staged KC = 32 at a time through a double-buffered
+// LDS ring with ONE barrier per chunk.  The shipped 128x128 tile runs EIGHT waves (8 x 64x32 or 8 x 32x64, chosen per
+// loader pair in gemm_launch.h): at two blocks per CU that is four waves per SIMD, which hides the load latency
+// better than four 64x64 waves did (-6..-20 % per kernel).  Measured anatomy on MI355X (tools/mfma_ablate.hip): the
+// MFMA stream alone runs at the 152 TF/s pipe peak (2.32 GHz); what costs is anything that sits BETWEEN a barrier
+// and the first MFMA.  Therefore
+//   * loaders are branch-free -- out-of-range lanes (SAME padding, ragged edges) get an out-of-range buffer offset
+//     and the hardware returns zeros, so the whole chunk body is one basic block the scheduler can interleave;
+//   * per-row state (byte offset, tap-validity mask) is hoisted out of the K loop; per chunk only a wave-uniform
+//     descriptor base changes;
+//   * the global loads of chunk c+2 and the LDS stores of chunk c+1 are issued in the gaps between the MFMA groups
+//     of chunk c (two register sets: 1.5 chunks between a load and its first use).
+// The "Q" / "R" loaders further down re-order rows and K so that the products with SAME-padding zeros are never
+// formed at all.
+// What did NOT help (measured, kept out): XCD-contiguous / n-tile-fastest block orders (-8..-20 %), pinning the
+// schedule with sched_barrier (-2 %), 256x256 (f32) and 16-wave 256x128 tiles (+3..+14 % time).
 // LDS tile formats (both conflict-free, guide section 2 / Guideline 4):
 //   KM ("k-minor"): tile[row][KC+4]; a lane reads 4 consecutive k with one ds_read_b128 (row
 //       stride 36 dwords spreads a 16-lane group over all 64 banks) and feeds 4 MFMAs.
