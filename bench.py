@@ -54,9 +54,46 @@ def cpu_baseline(batch, steps):
             threads = max(blas)
     except Exception:
         pass
-    return {"value": batch * steps / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s, "
-                      f"BLAS threads {threads} of {os.cpu_count()} logical CPUs (im2col/col2im parts are single-threaded)"}
+    numpy_rate = batch * steps / dt
+    out = {"value": numpy_rate, "unit": "frames/s", "cores": threads, "kind": "port",
+           "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s, "
+                     f"BLAS threads {threads} of {os.cpu_count()} logical CPUs (im2col/col2im parts are single-threaded)",
+           "numpy_oracle_frames_per_s": numpy_rate}
+    # second CPU statement of the same arithmetic: torch-CPU (oneDNN convs, autograd), all host threads
+    try:
+        import torch
+        from tests import _torch_ref as tref
+        nthreads = torch.get_num_threads()
+        tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+        ts, tc, tt = (torch.tensor(a) for a in (src, ctx, tgt))
+        tm = {k: torch.zeros_like(v) for k, v in tp.items()}
+        tv = {k: torch.zeros_like(v) for k, v in tp.items()}
+
+        def tstep(t):
+            loss = tref.forward(tp, ts, tc, tt, H, W, DF)["loss"]
+            grads = torch.autograd.grad(loss, list(tp.values()))
+            with torch.no_grad():                          # TF-Adam (train_script.py:128 defaults)
+                lr_t = 1e-4 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+                for (k, w), g in zip(tp.items(), grads):
+                    tm[k].mul_(0.9).add_(g, alpha=0.1)
+                    tv[k].mul_(0.999).addcmul_(g, g, value=0.001)
+                    w.sub_(lr_t * tm[k] / (tv[k].sqrt() + 1e-8))
+
+        tstep(1)
+        t0 = time.perf_counter()
+        for t in range(2, 2 + steps):
+            tstep(t)
+        dtt = time.perf_counter() - t0
+        torch_rate = batch * steps / dtt
+        out["torch_cpu_frames_per_s"] = torch_rate
+        if torch_rate > numpy_rate:
+            out.update(value=torch_rate, cores=nthreads,
+                       sample=f"{steps} fwd+bwd+Adam steps at batch {batch}, f32: torch-CPU statement (oneDNN, autograd, {nthreads} threads) "
+                              f"{dtt:.1f}s = {torch_rate:.1f} frames/s; numpy oracle ({threads} BLAS threads) {dt:.1f}s = {numpy_rate:.1f} frames/s; "
+                              f"{os.cpu_count()} logical CPUs")
+    except Exception as e:                                   # the numpy figure stands
+        out["torch_cpu_error"] = repr(e)[:200]
+    return out
 
 
 def main():
