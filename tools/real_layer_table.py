@@ -6,6 +6,10 @@ g=torch.Generator(device="cuda").manual_seed(0)
 fr=[torch.rand((B,36,64,3),device="cuda",generator=g)*2-1 for _ in range(3)]
 with Translator(36,64,featsize=100,max_batch=B,variant="real") as tr:
     tr.init_params(0)
+    for _ in range(2):                       # first launches load the code objects: keep them out of the table
+        tr.dev_forward_backward(*(t.data_ptr() for t in fr), B)
+        tr.dev_adam(1e-4)
+    tr.sync()
     ents=tr.profile_step(*(t.data_ptr() for t in fr), B, iters=3)
     tot=sum(e["ms"] for e in ents)
     print("total", tot)
