@@ -41,7 +41,7 @@ class CnnBuf(ctypes.Structure):
 
 
 class CnnOp(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("kind", "src", "dst", "dst_ch0", "kh", "kw", "stride", "same", "cout", "reserved")] + \
+    _fields_ = [(n, ctypes.c_int32) for n in ("kind", "src", "dst", "dst_ch0", "kh", "kw", "stride", "same", "cout", "lane")] + \
                [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
 
 
@@ -95,6 +95,7 @@ SIGNATURES = {
     "ctx_cnn_forward_u8": (_c.c_int, [_P, _U8, _c.c_int, _F]),
     "ctx_cnn_forward_dev": (_c.c_int, [_P, _P, _c.c_int, _c.POINTER(_P)]),
     "ctx_cnn_read_buffer": (_c.c_int, [_P, _c.c_int, _c.c_int, _F]),
+    "ctx_cnn_profile": (_c.c_int, [_P, _c.c_int, _c.c_int, _F, _c.c_int]),
     "ctx_cnn_stream": (_P, [_P]),
     "ctx_cnn_sync": (_c.c_int, [_P]),
 }

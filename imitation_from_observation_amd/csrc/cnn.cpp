@@ -34,8 +34,14 @@ struct ctx_cnn {
     int64_t weight_floats = 0;
     uint8_t* u8 = nullptr;
     float* f32in = nullptr;
-    float* slab = nullptr;
+    static constexpr int NLANE = 4;                   // branch lanes: lane 0 is `stream`
+    hipStream_t lane[NLANE] = {};
+    float* slab[NLANE] = {};                          // one split-K workspace per lane
     int64_t slab_floats = 0;
+    std::vector<hipEvent_t> done;                     // done[i]: op i finished (recorded on its lane)
+    std::vector<std::vector<int>> deps;               // deps[i]: ops on OTHER lanes that write op i's src buffer
+    hipEvent_t ev_fork = nullptr;
+    bool overlap = true;
     float* zeros = nullptr;
     std::string err;
 };
@@ -80,6 +86,7 @@ int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>
         const ctx_cnn_op& op = ops[i];
         if (op.src < 0 || op.dst < 0 || op.src >= (int)bufs.size() || op.dst >= (int)bufs.size() || op.src == op.dst)
             return cfail(nullptr, CTX_E_INVALID, "op %zu: bad buffer ids", i);
+        if (op.lane < 0 || op.lane >= ctx_cnn::NLANE) return cfail(nullptr, CTX_E_INVALID, "op %zu: lane %d outside [0,%d)", i, op.lane, ctx_cnn::NLANE);
         const ctx_cnn_buf &in = bufs[op.src], &out = bufs[op.dst];
         int ho, wo;
         ctx_cnn_op o = op;
@@ -99,31 +106,49 @@ int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>
     return CTX_OK;
 }
 
-int run(ctx_cnn* h, int n) {
-    const SplitWs ws{h->slab, h->slab_floats, h->precision};
-    for (const ctx_cnn_op& op : h->ops) {
+// One pass over the op list.  Ops of different lanes overlap (the branches of an Inception block are independent small
+// GEMMs that do not fill the chip alone); each op is ordered after the ops that wrote its src buffer, and the pass ends
+// with every lane joined into lane 0.  With `ev` (profiling) everything runs on lane 0, one event per op boundary.
+int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
+    const bool par = h->overlap && !ev;
+    if (par) {
+        (void)hipEventRecord(h->ev_fork, h->lane[0]);
+        for (int l = 1; l < ctx_cnn::NLANE; ++l) (void)hipStreamWaitEvent(h->lane[l], h->ev_fork, 0);
+    }
+    int last_on[ctx_cnn::NLANE] = {-1, -1, -1, -1};
+    for (size_t oi = 0; oi < h->ops.size(); ++oi) {
+        const ctx_cnn_op& op = h->ops[oi];
+        const int L = par ? op.lane : 0;
+        hipStream_t st = h->lane[L];
+        if (ev) (void)hipEventRecord((*ev)[oi], st);
+        if (par) for (int j : h->deps[oi]) (void)hipStreamWaitEvent(st, h->done[j], 0);
+        const SplitWs ws{h->slab[L], h->slab_floats, h->precision};
         const ctx_cnn_buf &in = h->bufs[op.src], &out = h->bufs[op.dst];
         const float* x = h->dbuf[op.src];
         float* y = h->dbuf[op.dst] + op.dst_ch0;
-        if (op.kind == CTX_CNN_MAXPOOL) { maxpool3x3s2(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
-        if (op.kind == CTX_CNN_AVGPOOL) { avgpool3x3s1(h->stream, x, y, n, in.h, in.w, in.c, out.c); continue; }
-        const int R = n * out.h * out.w;
-        const float* w = h->weights + op.w_off;
-        Epi ep;
-        ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
-        const int pady = op.same ? same_before(in.h, op.kh, op.stride) : 0, padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
-        if (n >= 64 && op.same && op.kh * op.kw > 1) {       // position-major: SAME-padding taps outside the grid are never multiplied
-            PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, in.c / KC);
-            g.KW = op.kw; g.padx = padx;
-            conv_fwd_q(h->stream, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, in.c, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
-            continue;
+        if (op.kind == CTX_CNN_MAXPOOL) maxpool3x3s2(st, x, y, n, in.h, in.w, in.c, out.c);
+        else if (op.kind == CTX_CNN_AVGPOOL) avgpool3x3s1(st, x, y, n, in.h, in.w, in.c, out.c);
+        else {
+            const int R = n * out.h * out.w;
+            const float* w = h->weights + op.w_off;
+            Epi ep;
+            ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
+            const int pady = op.same ? same_before(in.h, op.kh, op.stride) : 0, padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
+            if (n >= 64 && op.same && op.kh * op.kw > 1) {   // position-major: SAME-padding taps outside the grid are never multiplied
+                PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, in.c / KC);
+                g.KW = op.kw; g.padx = padx;
+                conv_fwd_q(st, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, in.c, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
+            } else {
+                KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
+                a.s = op.stride; a.K = op.kh; a.KW = op.kw; a.pad = pady; a.padx = padx;
+                NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
+                conv_fwd(st, a, b, ep, R, op.cout, ws);
+            }
         }
-        KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
-        a.s = op.stride; a.K = op.kh; a.KW = op.kw;
-        a.pad = pady; a.padx = padx;
-        NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
-        conv_fwd(h->stream, a, b, ep, R, op.cout, ws);
+        if (par) { (void)hipEventRecord(h->done[oi], st); last_on[L] = (int)oi; }
     }
+    if (par) for (int l = 1; l < ctx_cnn::NLANE; ++l) if (last_on[l] >= 0) (void)hipStreamWaitEvent(h->lane[0], h->done[last_on[l]], 0);
+    if (ev) (void)hipEventRecord((*ev)[h->ops.size()], h->lane[0]);
     if (hipGetLastError() != hipSuccess) return cfail(h, CTX_E_DEVICE, "kernel launch failed");
     return CTX_OK;
 }
@@ -161,7 +186,21 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     alloc((void**)&h->u8, npix * 3, false);
     alloc((void**)&h->f32in, npix * 3 * sizeof(float), false);
     h->slab_floats = 32ll << 20;
-    alloc((void**)&h->slab, (size_t)h->slab_floats * sizeof(float), false);
+    h->lane[0] = h->stream;
+    for (int l = 0; l < ctx_cnn::NLANE; ++l) {
+        alloc((void**)&h->slab[l], (size_t)h->slab_floats * sizeof(float), false);
+        if (l && ok) ok = hipStreamCreateWithFlags(&h->lane[l], hipStreamNonBlocking) == hipSuccess;
+    }
+    h->done.assign(nops, nullptr);
+    h->deps.assign(nops, {});
+    for (int i = 0; i < nops && ok; ++i) {
+        ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
+        for (int j = 0; j < i; ++j)
+            if (vo[j].dst == vo[i].src && vo[j].lane != vo[i].lane) h->deps[i].push_back(j);
+    }
+    if (ok) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    // measured at 192 images of 125x125: branch lanes -11 % in the split-bf16 mode, +2 % (and a slower chained train step) in f32
+    { const char* e = getenv("CTX_CNN_LANES"); h->overlap = e ? e[0] != '0' : precision == CTX_PREC_BF16X3; }
     alloc((void**)&h->zeros, 256, true);
     if (!ok) { cfail(nullptr, CTX_E_NOMEM, "device allocation failed"); ctx_cnn_destroy(h); return CTX_E_NOMEM; }
     *out = h;
@@ -173,7 +212,13 @@ void ctx_cnn_destroy(ctx_cnn* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (float* p : h->dbuf) if (p) (void)hipFree(p);
-    for (void* p : {(void*)h->weights, (void*)h->u8, (void*)h->f32in, (void*)h->slab, (void*)h->zeros}) if (p) (void)hipFree(p);
+    for (void* p : {(void*)h->weights, (void*)h->u8, (void*)h->f32in, (void*)h->zeros}) if (p) (void)hipFree(p);
+    for (int l = 0; l < ctx_cnn::NLANE; ++l) {
+        if (h->slab[l]) (void)hipFree(h->slab[l]);
+        if (l && h->lane[l]) { (void)hipStreamSynchronize(h->lane[l]); (void)hipStreamDestroy(h->lane[l]); }
+    }
+    for (hipEvent_t e : h->done) if (e) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -228,6 +273,29 @@ int ctx_cnn_read_buffer(ctx_cnn* h, int index, int n, float* out) {
     CNN_HIP(h, hipMemcpyAsync(out, h->dbuf[index], (size_t)n * b.h * b.w * b.c * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     CNN_HIP(h, hipStreamSynchronize(h->stream));
     return CTX_OK;
+}
+
+// per-op HIP-event times (ms) of one forward over the n images currently in buffer 0, averaged over `iters` passes;
+// ms[i] belongs to op i of the list given to ctx_cnn_create.  Measurement only.
+int ctx_cnn_profile(ctx_cnn* h, int n, int iters, float* ms, int max_ops) {
+    if (!h || !ms || n <= 0 || n > h->max_images || iters <= 0 || max_ops < (int)h->ops.size()) return CTX_E_INVALID;
+    CNN_HIP(h, hipSetDevice(h->device));
+    std::vector<hipEvent_t> ev(h->ops.size() + 1);
+    for (auto& e : ev) CNN_HIP(h, hipEventCreate(&e));
+    std::vector<double> acc(h->ops.size(), 0.0);
+    int rc = run(h, n);                                        // warm-up: code objects
+    for (int it = 0; it < iters && rc == CTX_OK; ++it) {
+        rc = run(h, n, &ev);
+        if (rc == CTX_OK && hipStreamSynchronize(h->stream) != hipSuccess) rc = cfail(h, CTX_E_DEVICE, "sync failed");
+        for (size_t i = 0; i < h->ops.size() && rc == CTX_OK; ++i) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+            acc[i] += t;
+        }
+    }
+    for (size_t i = 0; i < h->ops.size(); ++i) ms[i] = (float)(acc[i] / iters);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 void* ctx_cnn_stream(ctx_cnn* h) { return h ? (void*)h->stream : nullptr; }

@@ -86,6 +86,7 @@ class _Layout:
     def __init__(self, H, W):
         self.bufs, self.ops, self.convs, self.endpoints = [], [], [], OrderedDict()
         self.woff = 0
+        self.lane = 0                   # branch index inside a block: independent branches may overlap on the device
         x = self.new_buf(H, W, 3)
         for name, step in STEM:
             x = self.apply(x, step, "InceptionV3/")
@@ -140,14 +141,14 @@ class _Layout:
             _, scope, cout, k, stride, padding = step
             nw = k[0] * k[1] * src_c * cout
             op = dict(kind=_lib.CTX_CNN_CONV, src=x[0], dst=dst[0], dst_ch0=dst[1], kh=k[0], kw=k[1], stride=stride, same=int(padding == S),
-                      cout=cout, w_off=self.woff, b_off=self.woff + nw)
+                      cout=cout, w_off=self.woff, b_off=self.woff + nw, lane=self.lane)
             self.convs.append(dict(scope=prefix + scope, k=k, cin=x[3], cin_pad=src_c, cout=cout, w_off=self.woff, b_off=self.woff + nw))
             self.woff += (nw + cout + 3) // 4 * 4
         else:
             if x[3] != src_c:
                 raise ValueError("pooling a channel-padded tensor into a slice would copy the padding")
             op = dict(kind=_lib.CTX_CNN_MAXPOOL if step[0] == "max" else _lib.CTX_CNN_AVGPOOL, src=x[0], dst=dst[0], dst_ch0=dst[1],
-                      kh=3, kw=3, stride=2 if step[0] == "max" else 1, same=int(step[0] == "avg"), cout=0, w_off=0, b_off=0)
+                      kh=3, kw=3, stride=2 if step[0] == "max" else 1, same=int(step[0] == "avg"), cout=0, w_off=0, b_off=0, lane=self.lane)
         self.ops.append(op)
         return (dst[0], h, w, c)
 
@@ -162,8 +163,10 @@ class _Layout:
         out = self.new_buf(h, w, sum(s[2] for s in shapes))
         off = 0
         for bi, (br, sh) in enumerate(zip(branches, shapes)):
+            self.lane = bi % 4
             self.chain(x, br, f"{prefix}Branch_{bi}/", (out[0], off))
             off += sh[2]
+        self.lane = 0
         return out
 
 
@@ -184,7 +187,7 @@ class InceptionFrontend:
         self.out_shape = lay.out[1:]                       # (h, w, 2048)
         self.max_images = max_images
         bufs = (CnnBuf * len(self._bufs))(*[CnnBuf(*b) for b in self._bufs])
-        ops = (CnnOp * len(self._ops))(*[CnnOp(o["kind"], o["src"], o["dst"], o["dst_ch0"], o["kh"], o["kw"], o["stride"], o["same"], o["cout"], 0,
+        ops = (CnnOp * len(self._ops))(*[CnnOp(o["kind"], o["src"], o["dst"], o["dst_ch0"], o["kh"], o["kw"], o["stride"], o["same"], o["cout"], o["lane"],
                                                o["w_off"], o["b_off"]) for o in self._ops])
         from .translator import Translator
         self._h = ctypes.c_void_p()
@@ -285,6 +288,22 @@ class InceptionFrontend:
         out = np.empty((n, h, w, cp), np.float32)
         self._ck(self._lib.ctx_cnn_read_buffer(self._h, bid, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return out[..., :c]
+
+    def profile(self, n, iters=5):
+        """[(scope or pool kind, kernel shape, output grid, ms)] per op for the n images of the last forward (measurement)."""
+        ms = (ctypes.c_float * len(self._ops))()
+        self._ck(self._lib.ctx_cnn_profile(self._h, n, iters, ms, len(self._ops)))
+        convs = iter(self.convs)
+        out = []
+        for o, t in zip(self._ops, ms):
+            h, w, _ = self._bufs[o["dst"]]
+            if o["kind"] == _lib.CTX_CNN_CONV:
+                c = next(convs)
+                flops = 2.0 * n * h * w * c["k"][0] * c["k"][1] * c["cin"] * c["cout"]
+                out.append((c["scope"], f"{c['k'][0]}x{c['k'][1]} s{o['stride']} {'SAME' if o['same'] else 'VALID'} {c['cin']}->{c['cout']}", (h, w), float(t), flops))
+            else:
+                out.append(("maxpool" if o["kind"] == _lib.CTX_CNN_MAXPOOL else "avgpool", "3x3", (h, w), float(t), 0.0))
+        return out
 
     @property
     def stream(self):

@@ -201,13 +201,16 @@ int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n);
  *            filter [kh][kw][src channels (padded)][cout] at w_off, bias [cout] at b_off (floats into the blob);
  *            output written to channels [dst_ch0, dst_ch0 + cout) of buffer dst (tf.concat = adjacent slices).
  *   MAXPOOL  3x3 stride 2 VALID.     AVGPOOL  3x3 stride 1 SAME, mean over the taps inside the image.
- * Buffer 0 is the frame buffer (h, w, 32: channels 0..2 hold the frame); the LAST buffer is the output. */
+ * Buffer 0 is the frame buffer (h, w, 32: channels 0..2 hold the frame); the LAST buffer is the output.
+ * Every buffer is written once per pass (by one op, or by several ops into disjoint channel slices). */
 enum { CTX_CNN_CONV = 0, CTX_CNN_MAXPOOL = 1, CTX_CNN_AVGPOOL = 2 };
 typedef struct ctx_cnn_buf { int32_t h, w, c; } ctx_cnn_buf;
 typedef struct ctx_cnn_op {
     int32_t kind, src, dst, dst_ch0;
     int32_t kh, kw, stride, same;     /* CONV only; same: 1 = 'SAME', 0 = 'VALID' */
-    int32_t cout, reserved;
+    int32_t cout;
+    int32_t lane;                     /* 0..3: ops of different lanes may run concurrently (the branches of an Inception block);
+                                         the library orders every op after the writers of its src buffer */
     int64_t w_off, b_off;
 } ctx_cnn_op;
 typedef struct ctx_cnn ctx_cnn;
@@ -223,6 +226,8 @@ int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out);
  * Asynchronous on the handle's stream (ctx_cnn_stream / ctx_cnn_sync). */
 int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** d_out);
 int ctx_cnn_read_buffer(ctx_cnn* h, int index, int n, float* out);   /* end-point tests */
+/* Per-op HIP-event times (ms, averaged over `iters` passes over the n images currently in buffer 0); measurement only. */
+int ctx_cnn_profile(ctx_cnn* h, int n, int iters, float* ms, int max_ops);
 void* ctx_cnn_stream(ctx_cnn* h);
 int ctx_cnn_sync(ctx_cnn* h);
 
