@@ -321,7 +321,7 @@ const float* c4of(const ctx_handle* h, const float* p3) {
 }
 void pack_c4(ctx_handle* h, const float* p3, int64_t npix) { pack3to4(h->stream, p3, const_cast<float*>(c4of(h, p3)), npix); }
 
-SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.precision}; }
+SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.precision, h->gen ? 0 : 7}; }
 
 // Everything below enqueues on h->stream with h->slab / h->scratch; LaneSwap points those at the second lane
 // for the lifetime of a scope.  fork(): the second lane starts after everything enqueued so far on the

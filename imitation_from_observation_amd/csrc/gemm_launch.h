@@ -11,7 +11,7 @@ namespace ctx {
 void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);
 
 template <class LA, class LB, int MI, int NI, int WM, int WN>
-static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int nsplit) {
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     constexpr size_t lds = 2 * (size_t)(STile<LA::KM, TM, NT>::FLOATS + STile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
     static bool raised = false;
@@ -21,13 +21,18 @@ static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, const Epi
     }
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
     int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
-    if (ep.xcd_swizzle) nblk = (nblk + 7) / 8 * 8;
+    if (nblk < 64) ep.xcd_swizzle = 0;
+    if (ep.xcd_swizzle && ep.swz_group) {                 // grouped: one group = one (split, parity class); needs whole groups of 8
+        const int64_t grp = (int64_t)gm * gn * (nprob / 4);
+        if (grp % 8 == 0) ep.swz_group = (int)grp; else ep.xcd_swizzle = 0;
+    }
+    if (ep.xcd_swizzle && !ep.swz_group) nblk = (nblk + 7) / 8 * 8;
     dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL((igemm_split_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }
 
 template <class LA, class LB, int MI, int NI, int WM, int WN>
-static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, const Epi& ep, int M, int N, int nprob, int nsplit) {
+static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int nsplit) {
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
     constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM, NT>::FLOATS + Tile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
@@ -38,7 +43,12 @@ static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, const Epi& 
     }
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
     int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
-    if (ep.xcd_swizzle) nblk = (nblk + 7) / 8 * 8;
+    if (nblk < 64) ep.xcd_swizzle = 0;
+    if (ep.xcd_swizzle && ep.swz_group) {                 // grouped: one group = one (split, parity class); needs whole groups of 8
+        const int64_t grp = (int64_t)gm * gn * (nprob / 4);
+        if (grp % 8 == 0) ep.swz_group = (int)grp; else ep.xcd_swizzle = 0;
+    }
+    if (ep.xcd_swizzle && !ep.swz_group) nblk = (nblk + 7) / 8 * 8;
     dim3 grid((unsigned)nblk);
     hipLaunchKernelGGL((igemm_kernel<LA, LB, MI, NI, WM, WN>), grid, dim3(NT), lds, s, a, b, ep, M, N, nprob, nsplit, gm, gn);
 }

@@ -23,11 +23,11 @@ static int rect_avg_chunks(const RectGeo& g) {
 }
 int xcd_swz();
 void conv_wgrad_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmallR& b, Epi ep, int M, int N, SplitWs ws) {
-    ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = xcd_swz();
+    ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
     launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
 }
 void conv_wgrad2_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmall2R& b, Epi ep, int M, int N, SplitWs ws) {
-    ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = xcd_swz();
+    ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
     launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
 }
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {

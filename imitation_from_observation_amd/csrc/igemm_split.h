@@ -121,7 +121,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
 
     int rest = blockIdx.x;
     if (ep.xcd_swizzle) {                               // workgroups are dealt round-robin to the 8 XCDs: give each XCD a contiguous run of work
-        const int per = (int)gridDim.x >> 3, item = (rest & 7) * per + (rest >> 3);   // the launcher pads the grid to a multiple of 8
+        int item;
+        if (ep.swz_group) {
+            const int per = ep.swz_group >> 3, l = rest >> 3, grp = l / per;
+            item = grp * ep.swz_group + (rest & 7) * per + (l - grp * per);
+        } else {
+            const int per = (int)gridDim.x >> 3;            // the launcher pads the grid to a multiple of 8
+            item = (rest & 7) * per + (rest >> 3);
+        }
         if (item >= gm * gn * nprob * nsplit) return;
         rest = item;
     }                              // same block order as igemm_kernel

@@ -13,6 +13,7 @@ struct SplitWs {
     float* slab;
     int64_t slab_floats;
     int prec = 0;   // CTX_PREC_*: 0 exact-f32 MFMA, 1 split-bf16 (igemm_split.h)
+    int swz = 0;    // XCD-swizzle bits the caller allows (gemm_conv.hip: xcd_swz()); measured to pay only on ContextSkipNew's launches
 };
 
 // Each launcher computes D = A*B through igemm_kernel with the given loader pair; nprob problems
