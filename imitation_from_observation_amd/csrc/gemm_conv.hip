@@ -30,6 +30,13 @@ void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, floa
     ep.out1 = P; ep.ld1 = P3_LD;
     launch_igemm<KmCat2, KmPlain, false, 1, 2>(s, a, b, ep, M, 75, 1, 0, ws);
 }
+void convt3_product_t(hipStream_t s, const KmCat2& b, const float* w, int cb, float* PT, int M, SplitWs ws) {
+    // rows = the 75 filter rows (tap, c), columns = pixels: D[t][pixel] = sum_k w[t][k] * cat[pixel][k]
+    KmPlain a{w, cb, nullptr, 0, cb, 75, cb / KC, b.zeros};
+    Epi ep;
+    ep.out1 = PT; ep.ld1 = M;
+    launch_igemm<KmPlain, KmCat2, false, 1, 2>(s, a, b, ep, 75, M, 1, 0, ws);
+}
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }

@@ -85,6 +85,40 @@ __global__ __launch_bounds__(NTHREADS) void convt3_gather_s1_kernel(const float*
     }
 }
 
+// The same gather from a TAP-MAJOR product PT[(tap*3+c)][pixel] (convt3_product_t): for a fixed tap, neighbouring output
+// pixels read neighbouring entries, so the 75 loads of a thread are coalesced across the wave (the pixel-major layout above
+// costs 25 scattered 12-byte reads per thread: 0.42 ms at 2B*36*64 pixels against 0.1 ms here).
+__global__ __launch_bounds__(NTHREADS) void convt3_gather_s1_t_kernel(const float* __restrict__ PT, const float* __restrict__ bias,
+                                                                      float* __restrict__ out, int nimg, int hs, int ws) {
+    const int64_t total = (int64_t)nimg * hs * ws;
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
+        const int x = (int)(idx % ws);
+        const int y = (int)((idx / ws) % hs);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 5; ++ky) {
+            const int i = y + 2 - ky;
+            if ((unsigned)i >= (unsigned)hs) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int j = x + 2 - kx;
+                if ((unsigned)j >= (unsigned)ws) continue;
+                const float* r = PT + (int64_t)((ky * 5 + kx) * 3) * total + idx + (2 - ky) * ws + (2 - kx);
+                a0 += r[0]; a1 += r[total]; a2 += r[2 * total];
+            }
+        }
+        float* o = out + idx * 3;
+        o[0] = a0 + b0; o[1] = a1 + b1; o[2] = a2 + b2;
+    }
+}
+void convt3_gather_s1_t(hipStream_t s, const float* PT, const float* bias, float* out, int nimg, int hs, int ws) {
+    const int64_t total = (int64_t)nimg * hs * ws;
+    int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(convt3_gather_s1_t_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, PT, bias, out, nimg, hs, ws);
+}
+
 void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {
     const int64_t total = (int64_t)nimg * hs * ws;
     int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
