@@ -253,7 +253,11 @@ void build_params(const ctx_config& c, std::vector<ParamInfo>& out, int64_t& tot
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 template <class T>
-int dev_alloc(ctx_handle* h, T** p, int64_t count) {
+int dev_alloc(ctx_handle* h, T** p, int64_t count, bool whole_tensor = true) {
+    // the loaders address a tensor with 32-bit byte offsets (buffer descriptors, 0x80000000 = out-of-range marker)
+    if (whole_tensor && count * (int64_t)sizeof(T) >= (1ll << 31))
+        return fail(h, CTX_E_INVALID, "a %lld-byte activation buffer exceeds the 2 GiB the kernels address per tensor: lower max_batch",
+                    (long long)(count * sizeof(T)));
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, (size_t)count * sizeof(T));
     if (e != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%lld bytes): %s", (long long)(count * sizeof(T)), hipGetErrorString(e));
@@ -830,7 +834,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     if (rc == CTX_OK) {
         if (arena) h->arena = (float*)arena;
         else {
-            rc = dev_alloc(h, &h->arena, 4 * h->Ppad);
+            rc = dev_alloc(h, &h->arena, 4 * h->Ppad, false);     // addressed per parameter tensor, not as a whole
             h->own_arena = true;
         }
     }

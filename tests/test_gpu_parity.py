@@ -338,3 +338,10 @@ def test_device_phase_api_equals_host_api(T):
         # the torch-side view of the arena is the same memory
         np.testing.assert_array_equal(dp.engine.params[: dp.n_params].cpu().numpy(), ref.get_params_flat())
     dp.translator.close()
+
+
+def test_max_batch_beyond_32bit_offsets_is_refused(T):
+    """Loaders use 32-bit byte offsets per tensor: a max_batch whose activations would pass 2 GiB fails at create, with a message."""
+    from imitation_from_observation_amd import CtxError
+    with pytest.raises(CtxError, match="2 GiB"):
+        T(64, 64, 64, 1024, max_batch=8192)
