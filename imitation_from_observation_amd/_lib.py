@@ -46,6 +46,7 @@ class CnnOp(ctypes.Structure):
 
 
 CTX_CNN_CONV, CTX_CNN_MAXPOOL, CTX_CNN_AVGPOOL = 0, 1, 2
+BUCKET_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64)
 
 SIGNATURES = {
     "ctx_abi_version": (_c.c_int, []),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "ctx_eval": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _F, _F, _F]),
     "ctx_dev_forward_backward": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int]),
     "ctx_dev_forward": (_c.c_int, [_P, _P, _P, _P, _c.c_int]),
+    "ctx_set_grad_bucket_callback": (_c.c_int, [_P, _P, _P]),
     "ctx_dev_adam": (_c.c_int, [_P, _c.c_float]),
     "ctx_dev_scalars": (_c.c_int, [_P, _F]),
     "ctx_dev_params": (_P, [_P]),

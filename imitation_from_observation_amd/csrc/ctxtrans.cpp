@@ -96,6 +96,10 @@ struct ctx_handle {
     struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; };
     std::map<int, GraphSlot> graphs;
     bool use_graphs = true, capturing = false;
+    // data-parallel overlap: called from inside backward once the translate/* and deconv/* gradients are complete in the
+    // handle's stream order, so the caller can start their all-reduce while the encoders' backward is still being enqueued
+    ctx_bucket_fn bucket_fn = nullptr;
+    void* bucket_user = nullptr;
     // resident demo tensor (ctx_demos_upload): uint8 vdata[T][N][H*W*3], the x/127.5-1 table, index staging
     uint8_t* vdata = nullptr;
     int vT = 0, vN = 0;
@@ -372,6 +376,13 @@ struct Side {
 };
 constexpr int LANE_CTX = 0, LANE_DW = 1;
 
+// the tail of the gradient arena [first, Ppad) (translate/*, deconv/*: arena order is conv_context, conv, translate, deconv) is final
+void fire_bucket(ctx_handle* h, int64_t first) {
+    if (!h->bucket_fn) return;
+    if (use_lanes(h)) join(h, LANE_DW);          // their filter / bias gradients ran on the side lane
+    h->bucket_fn(h->bucket_user, 0, first, h->Ppad - first);
+}
+
 const char* const K_CONV = "igemm<ConvGather,Plain>";
 const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
 const char* const K_WGRAD = "igemm<WgradBig,WgradSmall>";
@@ -625,6 +636,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         e2.out1 = h->dZ + 2ll * B * F; e2.ld1 = F; e2.nsplit = F; e2.out2 = h->dcz; e2.ld2 = F;
         fc_dx(h, "translate/trans_h0", h->dth0, B, F, h->Wp("translate/trans_h0/Matrix"), 2 * F, e2);
     }
+    fire_bucket(h, h->find("translate/trans_h0/Matrix"));
     // ---- encoders
     auto encoder_bwd = [&](const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* dzp, float* const dA[5],
                            bool with_skips, int dw_lane) {
@@ -1082,6 +1094,12 @@ int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_c
     backward(h, B, sim_batch ? sim_batch : B);
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_set_grad_bucket_callback(ctx_handle* h, ctx_bucket_fn fn, void* user) {
+    if (!h) return CTX_E_INVALID;
+    h->bucket_fn = fn; h->bucket_user = user;
     return CTX_OK;
 }
 

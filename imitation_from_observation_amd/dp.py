@@ -14,6 +14,7 @@ HIP engine (cuda tensors, RCCL) and -- in the CPU test-suite -- on a gloo group 
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -52,9 +53,15 @@ class HipEngine:
             raise ValueError("frames must be contiguous float32 cuda tensors")
         return t.data_ptr()
 
-    def forward_backward(self, src, ctx, tgt, sim_batch):
+    def forward_backward(self, src, ctx, tgt, sim_batch, bucket_cb=None):
+        """bucket_cb(first, count): called from inside the backward pass once grads[first:first+count] are final."""
         B = src.shape[0]
-        self.translator.dev_forward_backward(self._ptr(src), self._ptr(ctx), self._ptr(tgt), B, sim_batch)
+        self.translator.set_grad_bucket_callback(bucket_cb)
+        try:
+            self.translator.dev_forward_backward(self._ptr(src), self._ptr(ctx), self._ptr(tgt), B, sim_batch)
+        finally:
+            if bucket_cb is not None:
+                self.translator.set_grad_bucket_callback(None)
 
     def adam(self, lr):
         self.translator.dev_adam(lr)
@@ -70,6 +77,10 @@ class DataParallelTrainer:
     def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, seed=1234, engine=None, precision=None):
         self.engine = engine or HipEngine(H, W, df_dim, featsize, max_batch, device, seed, precision)
         self.world = _world()
+        # CTX_DP_OVERLAP=1: bucketed all-reduce overlapped with the encoders' backward (opt-in until it has run on a
+        # multi-GPU node; the default is one all-reduce after backward).  CTX_DP_FORCE=1 runs the collectives at world 1 too.
+        self.overlap = os.environ.get("CTX_DP_OVERLAP", "0") == "1"
+        self.force_collectives = os.environ.get("CTX_DP_FORCE", "0") == "1"
         self.n_params = self.engine.n_params
         if self.world > 1:
             # replicas start identical.  Issued on the engine's stream (the collective orders itself after the
@@ -86,10 +97,24 @@ class DataParallelTrainer:
         B = src.shape[0]
         stream = getattr(self.engine, "stream", None)
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
-            self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world)
-            if self.world > 1:
-                # RCCL orders itself after the current stream = the stream the kernels run on
-                dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM)
+            if self.overlap and (self.world > 1 or self.force_collectives):
+                # two buckets: the tail of the arena (translate/*, deconv/*: final after the decoder's backward) is reduced
+                # while the encoders' backward runs; the head after it.  Collectives order themselves after the current stream.
+                works, split = [], [self.engine.grads.numel()]
+
+                def tail_ready(first, count):
+                    split[0] = first
+                    works.append(dist.all_reduce(self.engine.grads[first:first + count], op=dist.ReduceOp.SUM, async_op=True))
+
+                self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world, bucket_cb=tail_ready)
+                works.append(dist.all_reduce(self.engine.grads[:split[0]], op=dist.ReduceOp.SUM, async_op=True))
+                for w in works:
+                    w.wait()
+            else:
+                self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world)
+                if self.world > 1:
+                    # RCCL orders itself after the current stream = the stream the kernels run on
+                    dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM)
             self.engine.adam(lr)
 
     def scalars(self):

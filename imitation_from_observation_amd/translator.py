@@ -294,6 +294,16 @@ class Translator:
         self._ck(self._lib.ctx_dev_forward_backward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx),
                                                      ctypes.c_void_p(d_tgt), B, sim_batch))
 
+    def set_grad_bucket_callback(self, fn):
+        """fn(first, count) is called from inside dev_forward_backward when gradients [first, first+count) of the gradient
+        arena (translate/*, deconv/*) are final in stream order; None clears it (data-parallel overlap, dp.py)."""
+        if fn is None:
+            self._bucket_cb = None
+            self._ck(self._lib.ctx_set_grad_bucket_callback(self._h, None, None))
+            return
+        self._bucket_cb = _lib.BUCKET_FN(lambda user, bucket, first, count: fn(int(first), int(count)))   # keep the thunk alive
+        self._ck(self._lib.ctx_set_grad_bucket_callback(self._h, ctypes.cast(self._bucket_cb, ctypes.c_void_p), None))
+
     def dev_forward(self, d_src, d_ctx, d_tgt, B):
         self._ck(self._lib.ctx_dev_forward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt), B))
 

@@ -158,6 +158,13 @@ int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_c
 int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt,
                     int B);
 /* Fused multi-tensor Adam over the whole arena with the gradients currently in the grad arena. */
+/* Data-parallel overlap (new; the reference is single-device).  When set, ctx_dev_forward_backward calls fn(user, 0, first,
+ * count) on the calling thread as soon as gradients [first, first + count) of the gradient arena -- translate/ and deconv/,
+ * the tail of the arena -- are complete in the handle's stream order; the caller starts their all-reduce there (ordered
+ * after the handle's stream) while the encoders' backward is still being enqueued, and reduces [0, first) after the call
+ * returns.  fn == NULL clears it. */
+typedef void (*ctx_bucket_fn)(void* user, int bucket, int64_t first, int64_t count);
+int ctx_set_grad_bucket_callback(ctx_handle* h, ctx_bucket_fn fn, void* user);
 int ctx_dev_adam(ctx_handle* h, float lr);
 /* Synchronises and copies {loss, simloss, recon1, recon2} of the last forward. */
 int ctx_dev_scalars(ctx_handle* h, float scalars[4]);

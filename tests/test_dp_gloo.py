@@ -30,11 +30,14 @@ class OracleEngine:
         self.t = 0
         self._sc = torch.zeros(4, dtype=torch.float64)
 
-    def forward_backward(self, src, ctx, tgt, sim_batch):
+    def forward_backward(self, src, ctx, tgt, sim_batch, bucket_cb=None):
         self.p = o.unflatten(self.params.numpy().copy(), CFG)
         res, c = o.forward(self.p, src.numpy(), ctx.numpy(), tgt.numpy(), CFG)
         g = o.backward(self.p, c, CFG, sim_batch=sim_batch)
         self.grads.copy_(torch.from_numpy(o.flatten(g, CFG)))
+        if bucket_cb is not None:           # like the HIP engine: the tail of the arena (translate/*, deconv/*) is announced first
+            first = sum(int(np.prod(sh)) for n, sh in o.param_specs(CFG) if n.startswith("conv"))
+            bucket_cb(first, self.n_params - first)
         self._sc = torch.tensor([res["loss"], res["simloss"], res["recon1"], res["recon2"]], dtype=torch.float64)
 
     def adam(self, lr):
@@ -52,7 +55,8 @@ def _data(B):
     return [torch.from_numpy(rng.uniform(-1, 1, (B, 16, 16, 3))) for _ in range(3)]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap="0"):
+    os.environ["CTX_DP_OVERLAP"] = overlap          # "1": two buckets, the tail announced from inside the backward pass
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -81,12 +85,13 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_data_parallel_equals_full_batch():
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_two_rank_data_parallel_equals_full_batch(overlap):
     world = 2
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
