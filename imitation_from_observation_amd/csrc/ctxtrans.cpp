@@ -308,7 +308,7 @@ int alloc_buffers(ctx_handle* h) {
         TRY(dev_alloc(h, &h->dE[k], 2 * B * pix * ch));
     }
     TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
-    TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD));
+    TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
     TRY(dev_alloc(h, &h->dout4, 2 * B * h->npi / 3 * 4));
     int64_t maxc = std::max<int64_t>(h->D0, F);

@@ -91,7 +91,9 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     // (a 256x64 tile of four 64x64 waves for N <= 64 was measured: 1 block/CU, -15..-25 % vs 128x64; not kept)
-    const int MI = M > 64 ? 2 : 1, NI = N > 64 ? 2 : 1;
+    // 128-wide tiles unless they would be >= 20 % padding where 64-wide ones are not (192 images or 192 channels: 3 x 64, not 2 x 128)
+    auto wide = [](int X) { if (X <= 64) return 1; const int w128 = (X + 127) / 128 * 128, w64 = (X + 63) / 64 * 64; return (w128 - w64) * 5 >= w128 ? 1 : 2; };
+    const int MI = wide(M), NI = wide(N);
     const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
     // Split-K by a cost model, not a block-count target: a launch takes `rounds` passes over the resident
     // slots (256 CUs x blocks/CU allowed by LDS), so 400 or 800 blocks on 512 slots run at 78 % -- the split
