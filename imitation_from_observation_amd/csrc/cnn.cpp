@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,7 @@ struct ctx_cnn {
     hipEvent_t ev_fork = nullptr;
     bool overlap = true;
     float* zeros = nullptr;
+    bool stem4 = false;                               // buffer 0 is kept as [pixels][4] (see stem4_ok)
     std::string err;
 };
 
@@ -72,6 +74,21 @@ void out_dims(const ctx_cnn_buf& in, const ctx_cnn_op& op, int& ho, int& wo) {
 int same_before(int n, int k, int s) {
     const int out = (n + s - 1) / s, total = (out - 1) * s + k - n;
     return total > 0 ? total / 2 : 0;
+}
+
+// Buffer 0 holds 3 real channels.  When every reader is a square 3x3 / 5x5 conv it is stored 4 channels wide and those
+// convs run on the cin = 3 gather (K = 4 x taps instead of 32 x taps: Conv2d_1a_3x3 0.245 -> 0.05 ms at 192 x 125 x 125).
+bool stem4_ok(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>& ops) {
+    static const bool on = [] { const char* e = getenv("CTX_CNN_STEM4"); return !(e && e[0] == '0'); }();
+    bool any = false;
+    for (const ctx_cnn_op& op : ops) {
+        if (op.dst == 0) return false;
+        if (op.src != 0) continue;
+        if (op.kind != CTX_CNN_CONV || op.kh != op.kw || (op.kh != 3 && op.kh != 5)) return false;
+        if (op.same && same_before(bufs[0].h, op.kh, op.stride) != same_before(bufs[0].w, op.kw, op.stride)) return false;
+        any = true;
+    }
+    return on && any;
 }
 
 int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>& ops, int64_t weight_floats, int max_images) {
@@ -134,7 +151,13 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
             Epi ep;
             ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
             const int pady = op.same ? same_before(in.h, op.kh, op.stride) : 0, padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
-            if (n >= 64 && op.same && op.kh * op.kw > 1) {   // position-major: SAME-padding taps outside the grid are never multiplied
+            if (op.src == 0 && h->stem4) {
+                KmC3Gather a{x, in.h, in.w, out.h, out.w, R, h->zeros};
+                a.s = op.stride; a.pad = pady; a.K = op.kh;
+                NmC3Weights b{w, op.cout, h->zeros};
+                b.ntap = op.kh * op.kw; b.cs = in.c;
+                conv3_fwd(st, a, b, ep, R, op.cout, ws);
+            } else if (n >= 64 && op.same && op.kh * op.kw > 1) {   // position-major: SAME-padding taps outside the grid are never multiplied
                 PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, in.c / KC);
                 g.KW = op.kw; g.padx = padx;
                 conv_fwd_q(st, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, in.c, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
@@ -180,7 +203,8 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
         ok = hipMalloc(p, bytes) == hipSuccess && (!zero || hipMemset(*p, 0, bytes) == hipSuccess);
     };
     h->dbuf.assign(nbufs, nullptr);
-    for (int i = 0; i < nbufs; ++i) alloc((void**)&h->dbuf[i], (size_t)max_images * vb[i].h * vb[i].w * vb[i].c * sizeof(float), true);
+    h->stem4 = stem4_ok(vb, vo);
+    for (int i = 0; i < nbufs; ++i) alloc((void**)&h->dbuf[i], (size_t)max_images * vb[i].h * vb[i].w * (i == 0 && h->stem4 ? 4 : vb[i].c) * sizeof(float), true);
     alloc((void**)&h->weights, (size_t)weight_floats * sizeof(float), true);
     const size_t npix = (size_t)max_images * vb[0].h * vb[0].w;
     alloc((void**)&h->u8, npix * 3, false);
@@ -243,7 +267,7 @@ int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out) {
     for (int i0 = 0; i0 < n; i0 += h->max_images) {
         const int m = n - i0 < h->max_images ? n - i0 : h->max_images;
         CNN_HIP(h, hipMemcpyAsync(h->u8, frames + (int64_t)i0 * pix_in * 3, (size_t)m * pix_in * 3, hipMemcpyHostToDevice, h->stream));
-        pad_channels_u8(h->stream, h->u8, h->dbuf[0], m * pix_in, b0.c);
+        pad_channels_u8(h->stream, h->u8, h->dbuf[0], m * pix_in, h->stem4 ? 4 : b0.c);
         const int rc = run(h, m);
         if (rc != CTX_OK) return rc;
         if (out) CNN_HIP(h, hipMemcpyAsync(out + (int64_t)i0 * per_out, h->dbuf.back(), (size_t)m * per_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -258,7 +282,7 @@ int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** 
     if (!h || !d_frames || n <= 0 || n > h->max_images) return h ? cfail(h, CTX_E_INVALID, "n must be in [1, max_images]") : CTX_E_INVALID;
     CNN_HIP(h, hipSetDevice(h->device));
     const ctx_cnn_buf& b0 = h->bufs.front();
-    pad_channels_f32(h->stream, d_frames, h->dbuf[0], (int64_t)n * b0.h * b0.w, b0.c);
+    pad_channels_f32(h->stream, d_frames, h->dbuf[0], (int64_t)n * b0.h * b0.w, h->stem4 ? 4 : b0.c);
     const int rc = run(h, n);
     if (rc != CTX_OK) return rc;
     if (d_out) *d_out = h->dbuf.back();
@@ -270,6 +294,12 @@ int ctx_cnn_read_buffer(ctx_cnn* h, int index, int n, float* out) {
     if (!h || !out || index < 0 || index >= (int)h->bufs.size() || n <= 0 || n > h->max_images) return CTX_E_INVALID;
     const ctx_cnn_buf& b = h->bufs[index];
     CNN_HIP(h, hipSetDevice(h->device));
+    if (index == 0 && h->stem4) {                     // stored 4 wide; the caller sees the declared (padded) width
+        CNN_HIP(h, hipStreamSynchronize(h->stream));
+        memset(out, 0, (size_t)n * b.h * b.w * b.c * sizeof(float));
+        CNN_HIP(h, hipMemcpy2D(out, (size_t)b.c * sizeof(float), h->dbuf[0], 16, 16, (size_t)n * b.h * b.w, hipMemcpyDeviceToHost));
+        return CTX_OK;
+    }
     CNN_HIP(h, hipMemcpyAsync(out, h->dbuf[index], (size_t)n * b.h * b.w * b.c * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     CNN_HIP(h, hipStreamSynchronize(h->stream));
     return CTX_OK;

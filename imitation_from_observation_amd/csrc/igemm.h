@@ -393,9 +393,10 @@ struct KmC3Gather {
     int R;
     const float* zeros;
     int s = 2, pad = 1;            // (1, 2) for the stride-1 layers of ContextAEReal
+    int K = 5;                     // 3: the Inception stem's first conv (3x3 VALID: pad 0)
     struct Pos { rsrc_t rs; int tap0; };
     struct Ctx { int pb, y0, x0, t8; };   // pb = pixel index of (s*i - pad, s*j - pad), may be negative; t8 < 0: row invalid
-    __device__ int nchunks_of(int) const { return 4; }
+    __device__ int nchunks_of(int) const { return (K * K + 7) >> 3; }
     __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(x4), 8 * chunk}; }
     __device__ void prep(int, int row, int k4, Ctx& c) const {
         const int j = row % ws, t = row / ws, i = t % hs, n = t / hs;
@@ -405,8 +406,8 @@ struct KmC3Gather {
     }
     __device__ float4 load(const Ctx& c, const Pos& q) const {
         const int tap = q.tap0 + c.t8;
-        const int ky = (tap * 13) >> 6, kx = tap - 5 * ky;       // tap / 5 for 0 <= tap < 32
-        const bool ok = (unsigned)tap < 25u && (unsigned)(c.y0 + ky) < (unsigned)hb && (unsigned)(c.x0 + kx) < (unsigned)wb;
+        const int ky = K == 5 ? (tap * 13) >> 6 : (tap * 11) >> 5, kx = tap - K * ky;       // tap / 5, tap / 3 for 0 <= tap < 32
+        const bool ok = (unsigned)tap < (unsigned)(K * K) && (unsigned)(c.y0 + ky) < (unsigned)hb && (unsigned)(c.x0 + kx) < (unsigned)wb;
         return bload4(q.rs, ok ? (uint32_t)(c.pb + ky * wb + kx) * 16u : OOB);
     }
 };
@@ -476,15 +477,16 @@ struct NmC3Weights {
     static constexpr bool KM = false;
     const float* w; int cb;
     const float* zeros;
+    int ntap = 25, cs = 3;         // cs = filter rows per tap (32 where the blob keeps cin padded: the CNN executor's stem)
     struct Pos { rsrc_t rs; int tap0; };
     struct Ctx { uint32_t v; int t; };
-    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(w + (int64_t)chunk * 24 * cb), 8 * chunk}; }
+    __device__ Pos pos(int, int chunk) const { return Pos{make_rsrc(w + (int64_t)chunk * 8 * cs * cb), 8 * chunk}; }
     __device__ void prep(int, int kk, int r4, Ctx& c) const {
         const int t = kk >> 2, ch = kk & 3;
         c.t = (ch < 3 && r4 < cb) ? t : 64;
-        c.v = (uint32_t)((t * 3 + ch) * cb + r4) * 4u;
+        c.v = (uint32_t)((t * cs + ch) * cb + r4) * 4u;
     }
-    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.tap0 + c.t < 25 ? c.v : OOB); }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.tap0 + c.t < ntap ? c.v : OOB); }
 };
 
 // Filter-gradient operand: k = output-grid pixel (img,i,j); rows = channels of the BIG tensor at the
