@@ -373,11 +373,23 @@ __global__ __launch_bounds__(NTHREADS) void colsum_partial_kernel(const float* _
     int64_t r1 = r0 + rows_per;
     if (r1 > rows) r1 = rows;
     float4 acc = zero4();
-    if (rl < rpb && c4 * 4 < C)
-        for (int64_t r = r0 + rl; r < r1; r += rpb) {
-            const float4 v = ldg4(x + r * C + c4 * 4);
+    if (rl < rpb && c4 * 4 < C) {
+        const float* px = x + c4 * 4;
+        const int64_t st = (int64_t)rpb * C;
+        int64_t r = r0 + rl;
+        for (; r + 3 * rpb < r1; r += 4 * rpb) {          // four loads in flight; summed in row order
+            const float* q = px + r * C;
+            const float4 v0 = ldg4(q), v1 = ldg4(q + st), v2 = ldg4(q + 2 * st), v3 = ldg4(q + 3 * st);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; r < r1; r += rpb) {
+            const float4 v = ldg4(px + r * C);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     if (rl == 0 && c4 * 4 < C) {
@@ -411,8 +423,17 @@ __global__ __launch_bounds__(NTHREADS) void colsum_final_kernel(const float* __r
     const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float acc = 0.f;
-    if (c < C)
-        for (int sl = ln; sl < nsl; sl += 8) acc += part[(int64_t)sl * ldp + c];
+    if (c < C) {
+        const float* q = part + c;
+        int sl = ln;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; sl + 56 < nsl; sl += 64) {                  // eight independent loads per trip (the stage is latency-bound)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += q[(int64_t)(sl + 8 * u) * ldp];
+        }
+        for (; sl < nsl; sl += 8) a[0] += q[(int64_t)sl * ldp];
+        acc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     sh[ln][cl] = acc;
     __syncthreads();
     if (ln == 0 && c < C) {

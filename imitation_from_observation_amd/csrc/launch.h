@@ -79,7 +79,7 @@ void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int6
             const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real = 0);
 
 // db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * max(C, 4) floats
-constexpr int COLSUM_SPLITS = 256;
+constexpr int COLSUM_SPLITS = 512;
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out);
 
 // g *= (act >= 0 ? 1 : 0.2)
