@@ -118,3 +118,55 @@ def test_split_precision_front_end():
         p = {k: v.astype(np.float64) for k, v in f.init_synthetic(3).items()}
         u8 = np.random.default_rng(2).integers(0, 256, (2, 125, 125, 3), dtype=np.uint8)
         assert relmax(f.features(u8), io.forward(p, preprocess_u8(u8).astype(np.float64))["Mixed_7c"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_three_channel_input_convs_any_kernel():
+    """The executor stores its 3-channel input 4 wide and runs every conv that reads it on the cin = 3 gather (`stem4_ok`,
+    cnn.cpp).  Inception only exercises 3x3 VALID stride 2 there; this op list reads the frames with a 5x5 SAME stride-2 and a
+    3x3 SAME stride-1 conv whose filters carry junk in the 29 padding rows per tap (never multiplied), and reads buffer 0 back."""
+    import ctypes
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import _lib
+    from imitation_from_observation_amd._lib import CnnBuf, CnnOp
+    from oracle.ctx_oracle import preprocess_u8
+    from tests._torch_ref import tf_conv_ks
+    lib = _lib.load()
+    H, W, n = 18, 20, 5
+    bufs = [(H, W, 32), (9, 10, 32), (H, W, 64)]
+    rng = np.random.default_rng(11)
+    blob, ops, ws = [], [], []
+    off = 0
+    for dst, k, s, cout in ((1, 5, 2, 32), (2, 3, 1, 40)):
+        w = rng.standard_normal((k, k, 32, cout)).astype(np.float32) * 0.2
+        b = rng.standard_normal(cout).astype(np.float32)
+        ops.append(CnnOp(_lib.CTX_CNN_CONV, 0, dst, 0, k, k, s, 1, cout, 0, off, off + w.size))
+        blob += [w.ravel(), b, np.zeros((-(w.size + cout)) % 4, np.float32)]
+        off += (w.size + cout + 3) // 4 * 4
+        ws.append((w, b, s))
+    blob = np.concatenate(blob)
+    h = ctypes.c_void_p()
+    cb = (CnnBuf * 3)(*[CnnBuf(*x) for x in bufs])
+    co = (CnnOp * 2)(*ops)
+    assert lib.ctx_cnn_create(cb, 3, co, 2, blob.size, 8, 0, 0, ctypes.c_void_p(0), ctypes.byref(h)) == _lib.CTX_OK
+    try:
+        FP = ctypes.POINTER(ctypes.c_float)
+        assert lib.ctx_cnn_set_weights(h, blob.ctypes.data_as(FP), blob.size) == _lib.CTX_OK
+        u8 = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+        assert lib.ctx_cnn_forward_u8(h, u8.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), n, None) == _lib.CTX_OK
+        x = preprocess_u8(u8)
+        raw0 = np.empty((n, H, W, 32), np.float32)
+        assert lib.ctx_cnn_read_buffer(h, 0, n, raw0.ctypes.data_as(FP)) == _lib.CTX_OK
+        np.testing.assert_array_equal(raw0[..., :3], x)
+        assert not raw0[..., 3:].any()
+        for bid, (w, b, s) in zip((1, 2), ws):
+            got = np.empty((n,) + bufs[bid], np.float32)
+            assert lib.ctx_cnn_read_buffer(h, bid, n, got.ctypes.data_as(FP)) == _lib.CTX_OK
+            cout = w.shape[3]
+            want = torch.relu(tf_conv_ks(torch.from_numpy(x).double(), torch.from_numpy(w[:, :, :3]).double(), torch.from_numpy(b).double(), s)).numpy()
+            np.testing.assert_allclose(got[..., :cout], want, rtol=1e-5, atol=1e-5)
+            assert not got[..., cout:].any()
+    finally:
+        lib.ctx_cnn_destroy(h)
