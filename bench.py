@@ -173,6 +173,10 @@ def main():
             "frac_f32_mfma_peak": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / PEAK_F32_MFMA,
             "algorithmic_hbm_GBps": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / 1e9,
             "frac_hbm_peak": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / PEAK_HBM,
+            # where the step sits on the roofline: its arithmetic intensity is far right of the ridge (peak flops / HBM
+            # bandwidth = 19.7 FLOP/B), so the HBM ceiling does not bind and the attainable rate is the MFMA peak
+            "arithmetic_intensity_flop_per_byte": FLOPS_FWD_BWD_PER_TRIPLE * B / (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED),
+            "ridge_flop_per_byte": PEAK_F32_MFMA / PEAK_HBM,
         },
     }
     if rank == 0:
