@@ -61,33 +61,9 @@ __global__ __launch_bounds__(NTHREADS) void convt3_gather_kernel(const float* __
     }
 }
 
-__global__ __launch_bounds__(NTHREADS) void convt3_gather_s1_kernel(const float* __restrict__ P, const float* __restrict__ bias,
-                                                                    float* __restrict__ out, int nimg, int hs, int ws) {
-    const int64_t total = (int64_t)nimg * hs * ws;
-    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
-    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
-        const int x = (int)(idx % ws);
-        const int64_t t = idx / ws;
-        const int y = (int)(t % hs), n = (int)(t / hs);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int ky = 0; ky < 5; ++ky) {
-            const int i = y + 2 - ky;
-            if ((unsigned)i >= (unsigned)hs) continue;
-            for (int kx = 0; kx < 5; ++kx) {
-                const int j = x + 2 - kx;
-                if ((unsigned)j >= (unsigned)ws) continue;
-                const float* r = P + (((int64_t)n * hs + i) * ws + j) * P3_LD + (ky * 5 + kx) * 3;
-                a0 += r[0]; a1 += r[1]; a2 += r[2];
-            }
-        }
-        float* o = out + idx * 3;
-        o[0] = a0 + b0; o[1] = a1 + b1; o[2] = a2 + b2;
-    }
-}
-
-// The same gather from a TAP-MAJOR product PT[(tap*3+c)][pixel] (convt3_product_t): for a fixed tap, neighbouring output
-// pixels read neighbouring entries, so the 75 loads of a thread are coalesced across the wave (the pixel-major layout above
-// costs 25 scattered 12-byte reads per thread: 0.42 ms at 2B*36*64 pixels against 0.1 ms here).
+// The stride-1 form (ContextAEReal's d_h4) gathers from a TAP-MAJOR product PT[(tap*3+c)][pixel] (convt3_product_t): for a
+// fixed tap, neighbouring output pixels read neighbouring entries, so the 75 loads of a thread are coalesced across the wave
+// (a pixel-major product costs 25 scattered 12-byte reads per thread: 0.42 ms at 2B*36*64 pixels against 0.1 ms here).
 __global__ __launch_bounds__(NTHREADS) void convt3_gather_s1_t_kernel(const float* __restrict__ PT, const float* __restrict__ bias,
                                                                       float* __restrict__ out, int nimg, int hs, int ws) {
     const int64_t total = (int64_t)nimg * hs * ws;
@@ -117,13 +93,6 @@ void convt3_gather_s1_t(hipStream_t s, const float* PT, const float* bias, float
     int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(convt3_gather_s1_t_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, PT, bias, out, nimg, hs, ws);
-}
-
-void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {
-    const int64_t total = (int64_t)nimg * hs * ws;
-    int64_t blocks = (total + NTHREADS - 1) / NTHREADS;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(convt3_gather_s1_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, P, bias, out, nimg, hs, ws);
 }
 
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws) {

@@ -49,7 +49,6 @@ constexpr int P3_LD = 80;                   // row stride of P (75 used)
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
 // stride-1 variant: out[n,y,x,c] = b[c] + sum_{ky,kx} P[(n, y+2-ky, x+2-kx)][(ky*5+kx)*3+c]
-void convt3_gather_s1(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
 // tap-major variant: PT[(tap*3+c)][M pixels] = w (75 x cb) times the concat input, then a coalesced gather
 void convt3_product_t(hipStream_t s, const KmCat2& b, const float* w, int cb, float* PT, int M, SplitWs ws);
 void convt3_gather_s1_t(hipStream_t s, const float* PT, const float* bias, float* out, int nimg, int hs, int ws);
