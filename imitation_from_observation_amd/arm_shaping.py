@@ -112,3 +112,66 @@ class ContextAEReal(ContextSkipNew):
     def __init__(self, gf_dim=64, df_dim=64, gfc_dim=1024, dfc_dim=1024, c_dim=3):
         super().__init__(gf_dim, df_dim, gfc_dim, dfc_dim, c_dim)
         self.featsize = 100
+
+
+class ContextAEInception2(ContextSkipNew):
+    """gym/envs/mujoco/arm_shaping.py:1786-1894 -- the translator of mode 'oursinception', built by the sampler as
+    `ContextAEInception2(strides=[1,2,1,2], kernels=[3,3,3,3], filters=[1024,1024,512,512])` (rllab/sampler/base.py:126)
+    on the Mixed_7c feature maps of the frozen Inception-v3 (`inception_frontend.InceptionFrontend` produces them from
+    frames; `oursinception.InceptionTranslator` chains the two).  Same constructor arguments and fetch names; `image` is
+    [src, ctx, tgt] FEATURE MAPS, float [3, B, h, w, 2048], and `out = decode + tgtctx` (:1890-1891)."""
+    variant = "inception2"
+
+    def __init__(self, strides, kernels, filters):
+        strides, kernels, filters = list(strides), list(kernels), list(filters)
+        d = filters[3] // 8 if len(filters) == 4 else 0
+        if strides != [1, 2, 1, 2] or kernels != [3, 3, 3, 3] or d <= 0 or filters != [16 * d, 16 * d, 8 * d, 8 * d]:
+            raise ValueError("libctxtrans builds ContextAEInception2 as strides [1,2,1,2], kernels [3,3,3,3], filters "
+                             f"[16d,16d,8d,8d] (the sampler's only instantiation, base.py:126); got {strides}, {kernels}, {filters}")
+        self.strides, self.kernels, self.filters = strides, kernels, filters
+        self.df_dim = self.gf_dim = d
+        self.featsize = 1024                               # hard-coded in build(), arm_shaping.py:1797
+        self.translator = None
+        for f in _FETCHES:
+            setattr(self, f, f)
+
+    def build(self, image, device=0, seed=None, precision=None):
+        shape = tuple(getattr(image, "shape", image))
+        if len(shape) != 5 or shape[0] != 3:
+            raise ValueError(f"expected (3, batch, h, w, C) feature maps, got {shape}")
+        self.batch_size, self.output_height, self.output_width, self.c_dim = shape[1:]
+        self.translator = Translator(self.output_height, self.output_width, self.df_dim, self.featsize, max_batch=self.batch_size,
+                                     device=device, variant=self.variant, C=self.c_dim, precision=precision)
+        if seed is not None:
+            self.translator.init_params(seed)
+        return self
+
+    def run(self, fetches, image, learning_rate=None):
+        single = isinstance(fetches, str)
+        names = [fetches] if single else list(fetches)
+        for n in names:
+            if n not in _FETCHES:
+                raise KeyError(f"unknown fetch {n!r}")
+        src, ctx, tgt = (np.asarray(x, np.float32) for x in image)
+        res, want = {}, set(names)
+        if "optimizer" in want:
+            if learning_rate is None:
+                raise ValueError("fetching the optimizer needs learning_rate")
+            res.update(self.translator.train_step(src, ctx, tgt, lr=learning_rate))
+            res["optimizer"] = None
+            want -= {"optimizer", "loss", "simloss", "recon1", "recon2"}
+            if want - {"image_trans"}:
+                raise ValueError("tensor fetches together with the optimizer are not supported; run them separately")
+        if "image_trans" in want:                          # base.py:132: image_trans = featreshape, the fed tensor itself
+            res["image_trans"] = np.stack([src, ctx, tgt])
+            want.discard("image_trans")
+        if "input_z" in want:
+            res["input_z"] = self.translator.encode_f32(src)
+        if want & {"translated_z", "out"} and not want & {"out2", "loss", "simloss", "recon1", "recon2"}:   # neither depends on tgt
+            res["out"], res["translated_z"] = self.translator.translate_f32(src, ctx)   # the demo-cache fetch, base.py:216-218
+        elif want - {"input_z"}:
+            res.update(self.translator.evaluate(src, ctx, tgt))
+            if "translated_z" in want:
+                res["translated_z"] = self.translator.translate_f32(src, ctx)[1]
+        out = [res[n] for n in names]
+        return out[0] if single else out
