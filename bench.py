@@ -122,10 +122,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # (the env switch: a one-rank RCCL group, to exercise the N > 1 code on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+        # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise land AFTER the
+        # JSON line at exit: flush it now so that the JSON line is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
 
     B = args.batch
     trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision=args.precision)
@@ -134,7 +140,7 @@ def main():
     src, ctx, tgt = (f.float() / 127.5 - 1.0 for f in frames)      # synthetic frames, train_script.py:16-19 scaling
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,6 +185,39 @@ def main():
             "ridge_flop_per_byte": PEAK_F32_MFMA / PEAK_HBM,
         },
     }
+    if dist.is_initialized():
+        # Outside the timed region: what one step spends in compute and what the gradient all-reduce costs alone, so that the
+        # per-N values can be read (exposed communication = ms_per_step - compute_ms; an overlapped schedule can hide at most
+        # min(allreduce_ms, backward time)).  Every rank runs it; rank 0 reports its own clock.
+        try:
+            eng = trainer.engine
+            nrep = 5
+            with torch.cuda.stream(eng.stream):
+                eng.forward_backward(src, ctx, tgt, sim_batch=B * world)
+                eng.adam(1e-4)
+            barrier()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(eng.stream):
+                for _ in range(nrep):
+                    eng.forward_backward(src, ctx, tgt, sim_batch=B * world)
+                    eng.adam(1e-4)
+            barrier()
+            compute_ms = 1e3 * (time.perf_counter() - t0) / nrep
+            with torch.cuda.stream(eng.stream):
+                dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            barrier()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(eng.stream):
+                for _ in range(nrep):
+                    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+            barrier()
+            ar_ms = 1e3 * (time.perf_counter() - t0) / nrep
+            nbytes = eng.grads.numel() * 4
+            line["comm"] = {"payload_MB": nbytes / 1e6, "allreduce_ms": ar_ms, "compute_ms_per_step": compute_ms,
+                            "busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if world > 1 else None,
+                            "overlap": os.environ.get("CTX_DP_OVERLAP", "0") == "1"}
+        except Exception as e:                      # diagnostics must never cost the bench line
+            line["comm"] = {"error": repr(e)}
     if rank == 0:
         # dominant kernel: timed with HIP events on the handle's stream
         tr = trainer.translator
@@ -233,8 +272,10 @@ def main():
             del t2
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(batch=32, steps=3)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
