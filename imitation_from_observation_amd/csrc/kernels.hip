@@ -427,7 +427,10 @@ void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, 
     const int tpr = c4 < NTHREADS ? c4 : NTHREADS;
     const int rpb = NTHREADS / tpr;
     int nsl = (int)((rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8));
-    if (nsl > COLSUM_SPLITS) nsl = COLSUM_SPLITS;
+    // 128 slabs, not the 512 that make this kernel fastest alone (0.30 vs 0.26 ms per step): it runs on the side lane beside
+    // the MFMA-bound chain, and the fewer CU slots it takes the less it slows that chain (whole step 14.50 vs 14.68 ms; tools/colsum_ab.sh)
+    static const int cap = [] { const char* e = getenv("CTX_COLSUM_SPLITS"); const int v = e ? atoi(e) : 128; return v < 1 ? 1 : v > COLSUM_SPLITS ? COLSUM_SPLITS : v; }();
+    if (nsl > cap) nsl = cap;
     if (nsl < 1) nsl = 1;
     const int64_t rows_per = (rows + nsl - 1) / nsl;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((c4 + tpr - 1) / tpr, nsl), dim3(NTHREADS), 0, s, x, rows, C, tpr, rows_per,
