@@ -856,12 +856,13 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
         h->overlap = !(ov && ov[0] == '0');
         const char* gr = getenv("CTX_GRAPHS");
         h->use_graphs = !(gr && gr[0] == '0');
-        // side lanes at the lowest stream priority: their blocks are dispatched after the main chain's (step -0.03 ms against
-        // equal priorities, +0.08 ms at the highest; CTX_LANE_PRIO=0 normal, 2 highest)
+        // Side-lane stream priority.  Lowest (CTX_LANE_PRIO=1) is -0.03 ms on the ContextSkipNew step and -0.7 ms on the
+        // split-bf16 config-4 step, but the f32 config-4 step (front end chained on the same stream) went from 7.8 to 17.4 ms
+        // with it: the default stays NORMAL.  2 = highest (+0.08 ms).
         const char* lp = getenv("CTX_LANE_PRIO");
         int prio_low = 0, prio_high = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        const int lane_prio = (lp && lp[0] == '0') ? 0 : (lp && lp[0] == '2') ? prio_high : prio_low;
+        const int lane_prio = (lp && lp[0] == '1') ? prio_low : (lp && lp[0] == '2') ? prio_high : 0;
         for (int l = 0; l < ctx_handle::NLANE && rc == CTX_OK; ++l)
             if (hipStreamCreateWithPriority(&h->aux[l], hipStreamNonBlocking, lane_prio) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming) != hipSuccess ||
