@@ -152,3 +152,28 @@ def test_real_position_major_batches(T):
         for n in g:
             assert relmax(gg[n], g[n]) < 1e-3, n
             assert np.linalg.norm(np.asarray(gg[n], np.float64) - g[n]) <= 2e-3 * np.linalg.norm(g[n]), n
+
+
+def test_real_split_bf16_mode_within_budget(T):
+    """CTX_PREC_BF16X3 on ContextAEReal (narrow 32-channel layers take the 64-wide split tiles): outputs and losses within
+    1e-4 of the float64 oracle -- the budget of the path is 1e-3 -- and the loss-weighted gradient within 1e-3 in L2."""
+    H, W, B = 36, 64, 3
+    cfg, p, fr = make(H, W, B, seed=9)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    res, c = r.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = r.backward(p, c, cfg)
+    with T(H, W, featsize=100, max_batch=B, variant="real", precision="bf16x3") as tr:
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(ev[k] - res[k]) <= 1e-4 * abs(res[k]) + 1e-6, k
+        assert relmax(ev["out"], res["out"]) < 1e-4 and relmax(ev["out2"], res["out2"]) < 1e-4
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        gg = tr.get_grads()
+        num = sum(float(np.sum((gg[n].astype(np.float64) - g[n]) ** 2)) for n in g)
+        den = sum(float(np.sum(g[n] ** 2)) for n in g)
+        assert (num / den) ** 0.5 < 1e-3
+        pred, feat = tr.translate(fr[0], fr[1][0])
+        c0 = np.broadcast_to(o.preprocess_u8(fr[1][0]), src.shape).astype(np.float64)
+        tres, _ = r.forward(p, src.astype(np.float64), c0, c0, cfg)
+        assert relmax(pred, tres["out"]) < 1e-4 and relmax(feat, tres["translated_z"]) < 1e-4
