@@ -2,7 +2,9 @@
 """bench.py -- translator training throughput on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either form works -- plain `python bench.py --gpus N` starts its N ranks itself by re-executing under
+     torch.distributed.run on 127.0.0.1 and relays rank 0's JSON line as the LAST line of stdout;
+     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` is used as launched.)
 
 One "step" = forward + backward + Adam of ContextSkipNew at 64x64x3 on a per-GPU batch of 256
 synthetic (src, ctx, tgt) frame triples that are already resident in HBM (BASELINE.json
@@ -31,76 +33,188 @@ PEAK_HBM = 8.0e12
 PEAK_BF16_MFMA = 2.5e15                            # dense; a split product costs 3 bf16 MFMA flops per algorithmic flop
 
 
-def cpu_baseline(batch, steps):
-    """The numpy oracle (a port of the reference's arithmetic; the reference's TensorFlow path cannot
-    run here) timed on the host cores on a bounded sample: `steps` train steps at batch `batch`."""
+def _median_min(ts):
+    ts = sorted(ts)
+    return ts[len(ts) // 2], ts[0]
+
+
+def cpu_baseline(batch=32, steps=10, budget_s=40.0):
+    """CPU statements of the same arithmetic on the host cores, on a bounded sample (the reference's TensorFlow path cannot
+    run here, so kind = "port").  Two workloads at batch `batch`:
+      * BASELINE configs[0]: forward + the three losses (no backward);
+      * the metric's workload: forward + backward + TF-Adam.
+    Two statements: torch-CPU (tests/_torch_ref.py: oneDNN convolutions + autograd) and the numpy oracle.  The thread count
+    is swept (8/16/32/64/128, capped by the machine) with short runs, then `steps` timed steps (after a warm-up) run at
+    the best count: median and min are reported, `value` is batch / median of the faster statement's train step."""
+    import torch
     from oracle import ctx_oracle as o
+    from tests import _torch_ref as tref
+    ncpu = os.cpu_count() or 1
     cfg = o.SkipNewConfig(H=H, W=W, df_dim=DF, gf_dim=DF, featsize=FEAT)
     p = o.init_params(cfg, 0, np.float32)
-    m = {k: np.zeros_like(v) for k, v in p.items()}
-    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
     rng = np.random.default_rng(0)
     src, ctx, tgt = (rng.uniform(-1, 1, (batch, H, W, 3)).astype(np.float32) for _ in range(3))
-    o.train_step(p, m, v, 1, src, ctx, tgt, 1e-4, cfg)          # warm-up (page-in, BLAS threads)
-    t0 = time.perf_counter()
-    for t in range(2, 2 + steps):
-        o.train_step(p, m, v, t, src, ctx, tgt, 1e-4, cfg)
-    dt = time.perf_counter() - t0
-    threads = os.cpu_count()
-    try:                                     # the threads numpy's BLAS actually runs the matmuls on
-        from threadpoolctl import threadpool_info
-        blas = [t["num_threads"] for t in threadpool_info() if t.get("user_api") == "blas"]
-        if blas:
-            threads = max(blas)
-    except Exception:
-        pass
-    numpy_rate = batch * steps / dt
-    out = {"value": numpy_rate, "unit": "frames/s", "cores": threads, "kind": "port",
-           "sample": f"{steps} fwd+bwd+Adam steps of the numpy oracle at batch {batch}, f32, {dt:.1f}s, "
-                     f"BLAS threads {threads} of {os.cpu_count()} logical CPUs (im2col/col2im parts are single-threaded)",
-           "numpy_oracle_frames_per_s": numpy_rate}
-    # second CPU statement of the same arithmetic (BASELINE.md section 3): torch-CPU (oneDNN convs, autograd), all host threads
+    t_begin = time.perf_counter()
+
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
+    ts, tc, tt = (torch.tensor(a) for a in (src, ctx, tgt))
+    tm = {k: torch.zeros_like(v) for k, v in tp.items()}
+    tv = {k: torch.zeros_like(v) for k, v in tp.items()}
+
+    def t_fwd():
+        with torch.no_grad():
+            return float(tref.forward(tp, ts, tc, tt, H, W, DF)["loss"])
+
+    def t_train(t):
+        loss = tref.forward(tp, ts, tc, tt, H, W, DF)["loss"]
+        grads = torch.autograd.grad(loss, list(tp.values()))
+        with torch.no_grad():                              # TF-Adam (train_script.py:128 defaults)
+            lr_t = 1e-4 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+            for (k, w), g in zip(tp.items(), grads):
+                tm[k].mul_(0.9).add_(g, alpha=0.1)
+                tv[k].mul_(0.999).addcmul_(g, g, value=0.001)
+                w.sub_(lr_t * tm[k] / (tv[k].sqrt() + 1e-8))
+
+    def timed_calls(fn, n):
+        out = []
+        for i in range(n):
+            t0 = time.perf_counter()
+            fn(i)
+            out.append(time.perf_counter() - t0)
+        return out
+
+    # thread sweep on the train step (1 warm-up + 2 timed per count)
+    counts = [c for c in (8, 16, 32, 64, 128) if c <= ncpu] or [ncpu]
+    sweep, step_no = {}, [0]
+
+    def train_once(_):
+        step_no[0] += 1
+        t_train(step_no[0])
+
+    torch.set_num_threads(counts[0])
+    train_once(0)                                            # global warm-up: allocator, oneDNN primitive caches
+    train_once(0)
+    for c in counts:
+        torch.set_num_threads(c)
+        train_once(0)
+        sweep[c] = min(timed_calls(train_once, 2))
+        if time.perf_counter() - t_begin > budget_s * 0.5:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    n_train = steps
+    est = sweep[best] * steps
+    left = budget_s - (time.perf_counter() - t_begin)
+    if est > left * 0.6:                                    # keep the default bench run within minutes
+        n_train = max(3, int(left * 0.6 / sweep[best]))
+    train_ts = timed_calls(train_once, n_train)
+    t_fwd()
+    fwd_ts = timed_calls(lambda i: t_fwd(), max(n_train, 3))
+    tr_med, tr_min = _median_min(train_ts)
+    fw_med, fw_min = _median_min(fwd_ts)
+
+    # the numpy oracle at the same thread count (its im2col / col2im parts are single-threaded)
+    numpy_info = {}
     try:
-        import torch
-        from tests import _torch_ref as tref
-        nthreads = torch.get_num_threads()
-        tp = {k: torch.tensor(v, requires_grad=True) for k, v in p.items()}
-        ts, tc, tt = (torch.tensor(a) for a in (src, ctx, tgt))
-        tm = {k: torch.zeros_like(v) for k, v in tp.items()}
-        tv = {k: torch.zeros_like(v) for k, v in tp.items()}
+        from threadpoolctl import threadpool_limits
+        m = {k: np.zeros_like(v) for k, v in p.items()}
+        v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+        with threadpool_limits(limits=best, user_api="blas"):
+            o.train_step(p, m, v, 1, src, ctx, tgt, 1e-4, cfg)
+            nts = timed_calls(lambda i: o.train_step(p, m, v, i + 2, src, ctx, tgt, 1e-4, cfg), 3)
+            nfs = timed_calls(lambda i: o.forward(p, src, ctx, tgt, cfg), 3)
+        nm, nmin = _median_min(nts)
+        fm, fmin = _median_min(nfs)
+        numpy_info = {"train_frames_per_s": batch / nm, "train_ms_median": 1e3 * nm, "train_ms_min": 1e3 * nmin,
+                      "fwd_loss_frames_per_s": batch / fm, "fwd_loss_ms_median": 1e3 * fm, "blas_threads": best, "steps": 3}
+    except Exception as e:                                   # the torch figure stands
+        numpy_info = {"error": repr(e)[:200]}
 
-        def tstep(t):
-            loss = tref.forward(tp, ts, tc, tt, H, W, DF)["loss"]
-            grads = torch.autograd.grad(loss, list(tp.values()))
-            with torch.no_grad():                          # TF-Adam (train_script.py:128 defaults)
-                lr_t = 1e-4 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
-                for (k, w), g in zip(tp.items(), grads):
-                    tm[k].mul_(0.9).add_(g, alpha=0.1)
-                    tv[k].mul_(0.999).addcmul_(g, g, value=0.001)
-                    w.sub_(lr_t * tm[k] / (tv[k].sqrt() + 1e-8))
+    value, stmt = batch / tr_med, "torch-CPU (oneDNN, autograd)"
+    if numpy_info.get("train_frames_per_s", 0) > value:
+        value, stmt = numpy_info["train_frames_per_s"], "numpy oracle"
+    return {
+        "value": value, "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": f"{n_train} fwd+bwd+Adam steps at batch {batch}, f32, {stmt}, {best} threads of {ncpu} logical CPUs "
+                  f"(best of a sweep over {sorted(sweep)}): median {1e3 * tr_med:.0f} ms, min {1e3 * tr_min:.0f} ms per step; "
+                  f"the reference's TensorFlow path cannot run here",
+        "statement": stmt,
+        "train_ms_median": 1e3 * tr_med, "train_ms_min": 1e3 * tr_min, "train_steps": n_train,
+        "thread_sweep_train_s_per_step": {str(k): round(v_, 4) for k, v_ in sorted(sweep.items())},
+        # BASELINE configs[0]: batch 32, encoder-decoder forward + the L2 / feature losses on CPU
+        "config1_fwd_loss": {"value": batch / fw_med, "unit": "frames/s", "cores": best, "ms_median": 1e3 * fw_med,
+                             "ms_min": 1e3 * fw_min, "steps": len(fwd_ts), "statement": "torch-CPU (oneDNN)"},
+        "numpy_oracle": numpy_info,
+        "wall_s": time.perf_counter() - t_begin,
+    }
 
-        tstep(1)
-        t0 = time.perf_counter()
-        for t in range(2, 2 + steps):
-            tstep(t)
-        dtt = time.perf_counter() - t0
-        torch_rate = batch * steps / dtt
-        out["torch_cpu_frames_per_s"] = torch_rate
-        if torch_rate > numpy_rate:
-            out.update(value=torch_rate, cores=nthreads,
-                       sample=f"{steps} fwd+bwd+Adam steps at batch {batch}, f32: torch-CPU statement (oneDNN, autograd, {nthreads} threads) "
-                              f"{dtt:.1f}s = {torch_rate:.1f} frames/s; numpy oracle ({threads} BLAS threads) {dt:.1f}s = {numpy_rate:.1f} frames/s; "
-                              f"{os.cpu_count()} logical CPUs")
-    except Exception as e:                                   # the numpy figure stands
-        out["torch_cpu_error"] = repr(e)[:200]
-    return out
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1), relay everything the ranks print to stderr and rank 0's JSON line -- alone -- as the last line of stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    rest = []
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            try:
+                json.loads(ln)
+                line = ln
+                continue
+            except ValueError:
+                pass
+        rest.append(ln)
+    if rest:
+        sys.stderr.write("\n".join(rest) + "\n")
+        sys.stderr.flush()
+    if line is None:
+        sys.stderr.write(f"bench.py: the {n}-rank run produced no JSON line (exit code {proc.returncode})\n")
+        return proc.returncode or 1
+    print(line, flush=True)
+    return proc.returncode
+
+
+def spawn_selftest(args):
+    """BENCH_SPAWN_SELFTEST=1: the launch / barrier / max-over-ranks / one-JSON-line plumbing on a gloo group with a sleep in
+    place of the train step, so `python bench.py --gpus 2` can be exercised on a box without GPUs (tests/test_bench_spawn.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    print(f"rank {rank} of {world} done", flush=True)        # noise the parent must keep off the last line
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": args.steps * world / float(dt), "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "selftest": True}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE config: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=5)
@@ -112,6 +226,11 @@ def main():
                     help="skip the extra bf16x3 measurement that a default (f32) run appends as line['bf16x3']")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # plain `python bench.py --gpus N`: start the ranks ourselves
+        raise SystemExit(spawn_ranks(args.gpus))
+    if os.environ.get("BENCH_SPAWN_SELFTEST") == "1":
+        return spawn_selftest(args)
+
     import torch
     import torch.distributed as dist
     from imitation_from_observation_amd.dp import DataParallelTrainer
@@ -120,7 +239,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # (the env switch: a one-rank RCCL group, to exercise the N > 1 code on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -147,19 +268,27 @@ def main():
     def timed(tr_):
         for _ in range(args.warmup):
             tr_.step(src, ctx, tgt, lr=1e-4)
+        # HIP events on the stream the kernels are launched on, one per step boundary: median / min step time beside the
+        # wall-clock mean that `value` is computed from
+        stream = tr_.engine.stream
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        evs[0].record(stream)
+        for i in range(args.steps):
             tr_.step(src, ctx, tgt, lr=1e-4)
+            evs[i + 1].record(stream)
         barrier()
         dt_ = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([dt_], device="cuda", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax.item())
-        return dt_, tr_.scalars()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        ev_ = {"median": per[len(per) // 2], "min": per[0], "max": per[-1], "mean": sum(per) / len(per)}
+        return dt_, tr_.scalars(), ev_
 
-    dt, scal = timed(trainer)
+    dt, scal, step_events = timed(trainer)
 
     ms = 1e3 * dt / args.steps
     value = args.steps * B * world / dt
@@ -174,6 +303,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
                    "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
         "loss_after": scal["loss"],
+        "step_ms_hip_events": step_events,          # rank 0's stream; `ms_per_step` / `value` are the wall-clock mean, max over ranks
         "step_rates": {
             "tflops_f32": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / 1e12,
             "frac_f32_mfma_peak": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / PEAK_F32_MFMA,
@@ -263,15 +393,16 @@ def main():
             # the same workload with split-bf16 products (CTX_PREC_BF16X3): reported beside, never as `value`
             del trainer
             t2 = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision="bf16x3")
-            dt2, scal2 = timed(t2)
+            dt2, scal2, ev2 = timed(t2)
             line["bf16x3"] = {"value": args.steps * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                              "step_ms_hip_events": ev2,
                               "tflops_algorithmic": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt2 / args.steps) / 1e12,
                               "loss_after": scal2["loss"], "loss_rel_diff_vs_f32": abs(scal2["loss"] - scal["loss"]) / abs(scal["loss"]),
                               "note": "products a*b evaluated as hi*hi + hi*lo + lo*hi on bf16 MFMA with f32 accumulation "
                                       "(~1e-5 relative, tests/test_gpu_split.py); everything else f32"}
             del t2
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(batch=32, steps=3)
+            line["cpu_baseline"] = cpu_baseline(batch=32, steps=10)
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
