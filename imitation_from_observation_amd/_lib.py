@@ -86,6 +86,7 @@ SIGNATURES = {
     "ctx_stream": (_P, [_P]),
     "ctx_sync": (_c.c_int, [_P]),
     "ctx_dev_outputs": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P)]),
+    "ctx_last_codes": (_c.c_int, [_P, _F, _F, _c.POINTER(_c.c_int)]),
     "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
                                     _c.POINTER(_c.c_int)]),
     "ctx_debug_read": (_c.c_int, [_P, _c.c_char_p, _F, _c.c_size_t]),

@@ -96,9 +96,7 @@ class ContextSkipNew:
             if "image_trans" in want:
                 res["image_trans"] = np.stack(f)
             if "translated_z" in want or "input_z" in want:
-                B, F = f[0].shape[0], self.featsize
-                z = self.translator.debug_read("Z", 3 * B * F).reshape(3, B, F)   # [trans_z | tgt_z | src_z]
-                res["translated_z"], res["input_z"] = z[0], z[2]
+                res["input_z"], res["translated_z"] = self.translator.last_codes()   # stride-aware (ContextAEReal pads its rows)
         out = [res[n] for n in names]
         return out[0] if single else out
 

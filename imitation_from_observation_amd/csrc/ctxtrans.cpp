@@ -1147,6 +1147,19 @@ int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const 
     return CTX_OK;
 }
 
+int ctx_last_codes(ctx_handle* h, float* input_z, float* translated_z, int* Bout) {
+    if (!h) return CTX_E_INVALID;
+    if (h->last_B <= 0) return fail(h, CTX_E_STATE, "no training-mode forward has run");
+    const int B = h->last_B;
+    if (Bout) *Bout = B;
+    if (!input_z && !translated_z) return CTX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t row = (size_t)h->F * sizeof(float), pitch = (size_t)h->Fp * sizeof(float);
+    if (input_z) HIP_TRY(h, hipMemcpy2DAsync(input_z, row, h->Z + 2ll * B * h->Fp, pitch, row, B, hipMemcpyDeviceToHost, h->stream));
+    if (translated_z) HIP_TRY(h, hipMemcpy2DAsync(translated_z, row, h->Z, pitch, row, B, hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
 int ctx_train_step(ctx_handle* h, const float* src, const float* ctxf, const float* tgt, int B, float lr, float scalars[4]) {
     TRY(check_B(h, B));
     if (!src || !ctxf || !tgt) return fail(h, CTX_E_INVALID, "NULL input");

@@ -24,6 +24,9 @@ class TranslatorReward:
         self.ablation_type, self.batch_size = ablation_type, int(batch_size)
         self.skip = 2 if name in ("real", "sweep") else 1        # base.py:209-211
         self.means, self.imgs = None, None
+        self.validdata = None                                    # set_demos(): the cache is then built lazily on the first path
+        # mode 'oursinception' caps the demo videos at 50 (base.py:203-204); every other mode uses them all
+        self.nvideos_cap = 50 if hasattr(translator, "front") else None
 
     @classmethod
     def for_sampler(cls, name, imsize, nvp, scale, modelname=None, ablation_type="None", batch_size=25,
@@ -55,14 +58,25 @@ class TranslatorReward:
         """env_infos['imgs'] holds, every other step, a list over viewpoints of uint8 frames (base.py:193)."""
         return [img for img in path["env_infos"]["imgs"] if img is not None]
 
+    def set_demos(self, validdata):
+        """np.load(self.algo._kwargs['modeldata']) (base.py:198), kept for the lazy cache build of process_paths."""
+        self.validdata = np.asarray(validdata)
+        return self
+
     def build_demo_cache(self, validdata, first_frames, distributed=False):
         """validdata: demo tensor [T, Nvid, H, W, 3] in [-1,1] (np.load(modeldata), base.py:198);
         first_frames[vp]: uint8 context frame = first frame of the current rollout (base.py:200).
+        In mode 'oursinception' only the first 50 videos are used (`nvideos = 50`, base.py:203-204) and the reference feeds
+        `validdata[::skip, i]` to its uint8 placeholder WITHOUT the (x+1)*127.5 conversion (:212-213) -- so a uint8 demo
+        tensor is taken as it is there; a float one is converted like in the other modes (deviations).
         distributed=True (inside an initialised torch.distributed group, one rank per GPU): the demo videos
         are sharded rank::world, every rank translates its shard and the partial feature / frame sums are
         combined with ONE all-reduce per viewpoint -- the demo means are a plain sum over videos."""
         validdata = np.asarray(validdata)
         nvid = validdata.shape[1]
+        if self.nvideos_cap is not None:
+            nvid = min(nvid, self.nvideos_cap)
+        raw_u8 = validdata.dtype == np.uint8
         bs = self.batch_size
         self.means, self.imgs = [], []
         per_call = max(1, self.tr.max_batch // bs)
@@ -80,7 +94,8 @@ class TranslatorReward:
             for i0 in range(0, len(mine), per_call):
                 vids = mine[i0:i0 + per_call]
                 # ((validdata[::skip, i] + 1) * 127.5).astype(np.uint8), base.py:215
-                u8 = np.concatenate([((validdata[::self.skip, i][:bs] + 1) * 127.5).astype(np.uint8) for i in vids])
+                u8 = np.concatenate([validdata[::self.skip, i][:bs] if raw_u8 else
+                                     ((validdata[::self.skip, i][:bs] + 1) * 127.5).astype(np.uint8) for i in vids])
                 timg, tfeat = self.tr.translate(u8, ctx)                   # [translated_z, out], base.py:216-218
                 fsum += tfeat.reshape(len(vids), bs, -1).sum(0)
                 isum += timg.reshape((len(vids), bs) + pshape).sum(0)
@@ -113,7 +128,11 @@ class TranslatorReward:
             if len(f) != bs:
                 raise ValueError(f"a path has {len(f)} rendered frames, the sampler's placeholder holds {bs} (base.py:115)")
         if self.means is None:
-            raise RuntimeError("build_demo_cache() first (the reference builds it lazily on the first path)")
+            if self.validdata is None:
+                raise RuntimeError("no demo cache: call build_demo_cache(validdata, first_frames), or set_demos(validdata) to have it "
+                                   "built on the first path like the reference (base.py:195-223)")
+            # `context = imgs[0][vp]`: the first rendered frame of the FIRST path, per viewpoint (base.py:200)
+            self.build_demo_cache(self.validdata, [frames[0][0][vp] for vp in range(self.nvp)])
         costs = np.zeros((len(paths), bs), np.float32)
         per_call = max(1, self.tr.max_batch // bs)
         for vp in range(self.nvp):
@@ -130,8 +149,9 @@ class TranslatorReward:
 
     # ------------------------------------------------------------------ base.py:256-257
     def process_paths(self, paths):
-        """In place: path['rewards'][2j+1] -= costs[j] * j**2.  Builds the demo cache lazily like the reference
-        when `self.validdata` was provided."""
+        """In place: path['rewards'][2j+1] -= costs[j] * j**2.  After set_demos(validdata) the demo cache is built lazily from
+        the first path's first frame per viewpoint, as the reference does (base.py:195-200); otherwise build_demo_cache() must
+        have been called."""
         costs = self.paths_costs(paths)
         for p, c in zip(paths, costs):
             for j in range(self.batch_size):

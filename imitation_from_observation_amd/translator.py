@@ -165,17 +165,31 @@ class Translator:
         m, v = _f32(m, (self.n_params,)), _f32(v, (self.n_params,))
         self._ck(self._lib.ctx_set_adam_state(self._h, _fp(m), _fp(v), m.size, int(step)))
 
+    @staticmethod
+    def checkpoint_file(path):
+        """The file a checkpoint path names.  The reference's Saver paths carry no extension
+        ('.../model_%d_%.2f_%.2f_%.2f_%.2f', train_script.py:181-182) and np.savez would silently append one: both save()
+        and load() therefore use  path  if it ends in '.npz', else  path + '.npz'."""
+        path = os.fspath(path)
+        return path if path.endswith(".npz") else path + ".npz"
+
     def save(self, path, with_adam=True, prefix=""):
-        """Checkpoint keyed by the TF variable names (the Saver's, train_script.py:181)."""
+        """Checkpoint keyed by the TF variable names (the Saver's, train_script.py:181).  Returns the file written."""
         tree = {prefix + k: v for k, v in self.get_params().items()}
         if with_adam:
             m, v, step = self.get_adam_state()
             tree["__adam_m__"], tree["__adam_v__"], tree["__adam_step__"] = m, v, np.int64(step)
-        np.savez(path, **tree)
+        fn = self.checkpoint_file(path)
+        with open(fn, "wb") as f:                           # an open handle: numpy does not rename it
+            np.savez(f, **tree)
+        return fn
 
     def load(self, path, prefix=""):
         """saver.restore (base.py:144-145): accepts names with or without the 'contextmodel/' scope."""
-        with np.load(path) as z:
+        fn = self.checkpoint_file(path)
+        if not os.path.exists(fn) and os.path.exists(os.fspath(path)):
+            fn = os.fspath(path)                            # an .npz stored under an extension-less name
+        with np.load(fn) as z:
             keys = set(z.files)
             first = self.param_info()[0][0]
             if prefix + first not in keys and "contextmodel/" + first in keys:
@@ -349,6 +363,16 @@ class Translator:
             t["flops"] += e["flops"]
             t["launches"] += 1
         return dict(sorted(tab.items(), key=lambda kv: -kv[1]["ms"]))
+
+    def last_codes(self):
+        """(input_z, translated_z) [B, featsize] of the last training-mode forward (evaluate / train_step): the fetches
+        `model.input_z` / `model.translated_z` next to the losses (arm_shaping.py:1298, :1312), row padding removed."""
+        B = ctypes.c_int()
+        self._ck(self._lib.ctx_last_codes(self._h, None, None, ctypes.byref(B)))
+        iz = np.empty((B.value, self.featsize), np.float32)
+        tz = np.empty((B.value, self.featsize), np.float32)
+        self._ck(self._lib.ctx_last_codes(self._h, _fp(iz), _fp(tz), ctypes.byref(B)))
+        return iz, tz
 
     def debug_read(self, name, n):
         out = np.empty(int(n), np.float32)

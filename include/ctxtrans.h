@@ -177,6 +177,11 @@ int ctx_sync(ctx_handle* h);
  * input_z / translated_z [B,featsize]. */
 int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const float** input_z,
                     const float** translated_z);
+/* Host copies of model.input_z / model.translated_z [B, featsize] (arm_shaping.py:1298, :1312) of the last training-mode
+ * forward (ctx_eval / ctx_train_step* / ctx_dev_forward*), i.e. sess.run([..., input_z, translated_z], feed) next to the
+ * losses; rows are de-padded (the device keeps them at a stride of featsize rounded up to 32 for CTX_VARIANT_REAL).
+ * Either pointer may be NULL; *B (nullable) receives the batch of that forward. */
+int ctx_last_codes(ctx_handle* h, float* input_z, float* translated_z, int* B);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* One entry per launch group of a train step (a layer's forward, input gradient, filter gradient,

@@ -42,7 +42,7 @@ def test_param_total_is_the_references(built_lib):
 @pytest.mark.parametrize("kw", [dict(H=60), dict(W=40), dict(df_dim=48), dict(featsize=100), dict(max_batch=0), dict(C=1),
                                 dict(variant=7)])
 def test_bad_config_is_rejected(built_lib, kw):
-    base = dict(variant=0, H=64, W=64, C=3, df_dim=64, featsize=1024, max_batch=4, reserved=0)
+    base = dict(variant=0, H=64, W=64, C=3, df_dim=64, featsize=1024, max_batch=4, precision=0)
     base.update(kw)
     cfg = _lib.CtxConfig(**base)
     assert built_lib.ctx_param_total_for(ctypes.byref(cfg)) == _lib.CTX_E_INVALID
@@ -78,3 +78,12 @@ def test_product_package_never_imports_the_oracle(repo_root):
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("checker", ""), f"{f} mentions the oracle"
+
+
+def test_checkpoint_paths_without_extension_resolve_to_one_file(tmp_path):
+    """The reference's Saver paths have no extension (train_script.py:181-182); save and load must agree on the file."""
+    from imitation_from_observation_amd import Translator
+    p = str(tmp_path / "model_5000_12.30_4.00_5.00_0.00")
+    assert Translator.checkpoint_file(p) == p + ".npz"
+    assert Translator.checkpoint_file(p + ".npz") == p + ".npz"
+    assert Translator.checkpoint_file(tmp_path / "ck.npz") == str(tmp_path / "ck.npz")

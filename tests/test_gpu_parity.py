@@ -298,6 +298,10 @@ def test_checkpoint_roundtrip_and_tf_scope_prefix(T, tmp_path):
         a.train_step(src, ctx, tgt, lr=1e-3)
         a.save(tmp_path / "ck.npz", prefix="contextmodel/")          # train_script.py:120 scope
         b.load(tmp_path / "ck.npz")                                  # base.py:138 restores without it
+        # the reference's Saver paths carry no extension (train_script.py:181-182): save(p) then load(p) is one file
+        noext = str(tmp_path / "model_1_2.00_1.00_1.00_0.00")
+        assert a.save(noext, prefix="contextmodel/") == noext + ".npz"
+        b.load(noext)
         np.testing.assert_array_equal(a.get_params_flat(), b.get_params_flat())
         sa = a.train_step(src, ctx, tgt, lr=1e-3)
         sb = b.train_step(src, ctx, tgt, lr=1e-3)

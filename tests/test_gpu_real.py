@@ -106,6 +106,27 @@ def test_real_mirror_class(T):
     model.translator.close()
 
 
+def test_real_code_fetches_next_to_the_losses(T):
+    """`sess.run([loss, translated_z, input_z], feed)` on ContextAEReal with float frames -- the device keeps the
+    100-wide codes at a row stride of 128, the fetch must de-pad them (ctx_last_codes)."""
+    from imitation_from_observation_amd.arm_shaping import ContextAEReal
+    cfg, p, fr = make(36, 64, 3, seed=8)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    res, _ = r.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    model = ContextAEReal()
+    model.build((3, 3, 36, 64, 3))
+    model.translator.set_params(p)
+    loss, tz, iz, out2 = model.run([model.loss, model.translated_z, model.input_z, model.out2], [src, ctx, tgt])
+    assert tz.shape == (3, 100) and iz.shape == (3, 100)
+    assert abs(loss - res["loss"]) <= 1e-5 * res["loss"]
+    assert relmax(tz, res["translated_z"]) < 1e-5 and relmax(iz, res["input_z"]) < 1e-5 and relmax(out2, res["out2"]) < 1e-5
+    # the uint8 feed takes the sampler's preprocessing and the same path
+    tz8, iz8 = model.run([model.translated_z, model.input_z], fr)
+    np.testing.assert_array_equal(tz8, tz)
+    np.testing.assert_array_equal(iz8, iz)
+    model.translator.close()
+
+
 def test_real_golden_vectors(T):
     """HIP path vs the committed ContextAEReal fixture (tests/golden/make_golden.py:make_real)."""
     from tests.test_oracle_real import _load_real_golden

@@ -105,6 +105,36 @@ def test_ablations_and_errors():
         TranslatorReward(tr, 1, 0.5).build_demo_cache(validdata, first).paths_costs(paths)
 
 
+def test_lazy_cache_is_built_from_the_first_path_like_the_reference():
+    """base.py:195-200: without an explicit build the cache comes from np.load(modeldata) and `imgs[0][vp]` of the FIRST path."""
+    import copy
+    p, validdata, paths = make_world()
+    ref = reference_loop(p, validdata, copy.deepcopy(paths), nvp=2, scale=0.01)
+    hook = TranslatorReward(OracleTranslator(p, 50), nvp=2, scale=0.01, name="strike").set_demos(validdata)
+    costs = hook.process_paths(paths)
+    for k, (c, r) in enumerate(ref):
+        np.testing.assert_allclose(costs[k], c, rtol=2e-5)
+        np.testing.assert_allclose(paths[k]["rewards"], r, rtol=2e-5, atol=1e-6)
+
+
+def test_oursinception_mode_caps_the_demo_videos_at_50_and_takes_uint8_demos_as_they_are():
+    """base.py:203-204 (`nvideos = 50`) and :212-213 (the demo frames are fed without the (x+1)*127.5 conversion)."""
+    p, _, paths = make_world(nvp=1, npaths=1)
+    rng = np.random.default_rng(4)
+    demos = rng.integers(0, 256, (25, 53, H, W, 3), dtype=np.uint8)
+    first = [img for img in paths[0]["env_infos"]["imgs"] if img is not None][0]
+
+    class Incep(OracleTranslator):
+        front = object()                                   # what marks an InceptionTranslator
+
+    hook = TranslatorReward(Incep(p, 250), 1, 1.0).build_demo_cache(demos, first)
+    want = np.mean([o.translate(p, demos[:, i], first[0], CFG)[1] for i in range(50)], axis=0)
+    np.testing.assert_allclose(hook.means[0], want, rtol=1e-5, atol=1e-6)
+    allv = TranslatorReward(OracleTranslator(p, 250), 1, 1.0).build_demo_cache(demos, first)     # mode 'ours': every video
+    want53 = np.mean([o.translate(p, demos[:, i], first[0], CFG)[1] for i in range(53)], axis=0)
+    np.testing.assert_allclose(allv.means[0], want53, rtol=1e-5, atol=1e-6)
+
+
 def test_sweep_uses_every_other_demo_frame():
     p, _, paths = make_world(nvp=1, npaths=1)
     validdata = np.random.default_rng(1).uniform(-1, 1, (50, 3, H, W, 3)).astype(np.float32)
