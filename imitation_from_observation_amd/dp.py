@@ -112,7 +112,7 @@ class DataParallelTrainer:
                     w.wait()
             else:
                 self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world)
-                if self.world > 1:
+                if self.world > 1 or self.force_collectives:
                     # RCCL orders itself after the current stream = the stream the kernels run on
                     dist.all_reduce(self.engine.grads, op=dist.ReduceOp.SUM)
             self.engine.adam(lr)

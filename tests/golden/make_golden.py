@@ -126,7 +126,7 @@ def make_real(tag, cfg, B, pseed, stddev, frames, steps, lr=1e-4):
     print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     from oracle import ctx_oracle_real as r
     # ContextAEReal at the reference's sweep imsize (run_trpo_sweep_ours.py:64)
     make_real("real_f100_36x64_b3", r.RealConfig(), 3, 4321, 0.05, blob_frames, steps=3)
@@ -138,3 +138,110 @@ if __name__ == "__main__":
          blob_frames, steps=2)
     # the production net at the reference's init scale
     make("skipnew_d64_f1024_64x64_b2", o.SkipNewConfig(), 2, 1234, 0.02, synth_frames, steps=2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1] at its full size: the production net (47.6 M parameters), 64x64x3, batch 256.
+# The float64 oracle runs the batch in chunks (triples are independent except through the parameter-gradient sums and
+# the simloss mean, whose denominator is the global batch: `sim_batch`), so it needs ~10 GB and ~3 minutes here.
+# The fixture holds what a 1-2 MB file can: seeds (frames and parameters are regenerated from them), the four scalars,
+# a few whole output frames, per-image digests of out / out2 / translated_z / input_z, and for every parameter
+# gradient its digest, 16 random-sign projections (they cover every entry), and 4096 sampled entries.
+# For the lrelu' branch report: per activation buffer the number of negative entries and of entries within 1e-6 of zero
+# (relative to the buffer's max) -- the candidates an f32 pass can put on the other side of the kink.
+# ------------------------------------------------------------------------------------------------------------------
+B256_TAG = "b256_skipnew_d64_f1024_64x64"   # (not "skipnew_*": the small-fixture tests glob that)
+B256_SEEDS = dict(pseed=2024, fseed=(10, 11, 12), proj_seed=5, sample_seed=6)
+B256_NPROJ, B256_NSAMP = 16, 4096
+B256_KEEP = (0, 85, 170, 255)
+
+
+def b256_case():
+    """(cfg, params float64, uint8 frames) of the batch-256 fixture -- also used by the GPU test to rebuild the inputs."""
+    cfg = o.SkipNewConfig()
+    p = o.init_params(cfg, B256_SEEDS["pseed"], np.float64, stddev=0.02)
+    brng = np.random.default_rng(B256_SEEDS["pseed"] + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * 0.02
+    frames = [synth_frames(s, 256, cfg.H, cfg.W) for s in B256_SEEDS["fseed"]]
+    return cfg, p, frames
+
+
+def b256_probes(name_sizes):
+    """Per gradient tensor: random-sign projection vectors are too big to keep, so they are regenerated from a seed per
+    tensor; sampled entry indices likewise.  Returns {name: (seed_for_signs, sample_indices)}."""
+    out = {}
+    for i, (n, size) in enumerate(name_sizes):
+        rs = np.random.default_rng(B256_SEEDS["sample_seed"] * 1000 + i)
+        idx = np.sort(rs.choice(size, min(B256_NSAMP, size), replace=False))
+        out[n] = (B256_SEEDS["proj_seed"] * 1000 + i, idx)
+    return out
+
+
+def b256_project(a, seed):
+    """16 projections of the flat array on random +-1 vectors (generated 1 at a time: the tensors have up to 8.4 M entries)."""
+    a = np.asarray(a, np.float64).reshape(-1)
+    rng = np.random.default_rng(seed)
+    return np.array([float(a @ (rng.integers(0, 2, a.size, dtype=np.int8) * 2.0 - 1.0)) for _ in range(B256_NPROJ)])
+
+
+def make_b256(chunk=16):
+    import time
+    cfg, p, frames = b256_case()
+    B = 256
+    names = [n for n, _ in o.param_specs(cfg)]
+    g = {n: np.zeros_like(p[n]) for n in names}
+    scal = np.zeros(3)                                             # recon1, recon2, sum of squared code differences
+    outs = {k: [] for k in ("out", "out2", "translated_z", "input_z")}
+    act_stats = {}
+    t0 = time.time()
+    for i0 in range(0, B, chunk):
+        sl = slice(i0, i0 + chunk)
+        src, ctx, tgt = (o.preprocess_u8(f[sl]).astype(np.float64) for f in frames)
+        res, c = o.forward(p, src, ctx, tgt, cfg)
+        gi = o.backward(p, c, cfg, sim_batch=B)
+        for n in names:
+            g[n] += gi[n]
+        scal += [res["recon1"], res["recon2"], float(np.sum((c["trans_z"] - c["e_tgt"][5]) ** 2))]
+        for k in outs:
+            outs[k].append(res[k])
+        # lrelu'-relevant activations (the buffers whose sign the backward pass reads)
+        bufs = {}
+        for k in range(5):
+            bufs[f"s{k}_tgt"], bufs[f"s{k}_src"], bufs[f"c{k}"] = c["e_tgt"][k], c["e_src"][k], c["e_ctx"][k]
+        bufs["z_tgt"], bufs["z_src"], bufs["th0"] = c["e_tgt"][5], c["e_src"][5], c["trans_h0"]
+        for k in range(4):
+            bufs[f"d1_{k}"], bufs[f"d2_{k}"] = c["d1"][k], c["d2"][k]
+        for k, a in bufs.items():
+            st = act_stats.setdefault(k, [0, 0, 0.0])
+            st[0] += int((a < 0).sum())
+            st[2] = max(st[2], float(np.abs(a).max()))
+        for k, a in bufs.items():                                  # second pass needs the running max: use this chunk's (close enough for a count)
+            act_stats[k][1] += int((np.abs(a) <= 1e-6 * np.abs(a).max()).sum())
+        print(f"chunk {i0 // chunk + 1}/{B // chunk}  {time.time() - t0:.0f}s", flush=True)
+    sim = scal[2] / (B * cfg.featsize) * 1e3
+    fx = dict(cfg=np.array([cfg.H, cfg.W, cfg.C, cfg.df_dim, cfg.featsize]), B=B, stddev=0.02,
+              pseed=B256_SEEDS["pseed"], fseed=np.array(B256_SEEDS["fseed"]), proj_seed=B256_SEEDS["proj_seed"],
+              sample_seed=B256_SEEDS["sample_seed"], keep=np.array(B256_KEEP))
+    fx["param_digest"], _ = digest(o.flatten(p, cfg))
+    fx["scalars"] = np.array([scal[0] + scal[1] + sim, sim, scal[0], scal[1]])
+    for k in outs:
+        full = np.concatenate(outs[k])
+        fx[k + "_keep"] = full[list(B256_KEEP)].astype(np.float32)
+        flat = full.reshape(B, -1)
+        fx[k + "_rows"] = np.stack([flat.sum(1), np.abs(flat).sum(1), np.sqrt((flat * flat).sum(1))], 1)   # per-image digests
+    probes = b256_probes([(n, g[n].size) for n in names])
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_proj"] = np.stack([b256_project(g[n], probes[n][0]) for n in names])
+    fx["grad_samples"] = np.stack([np.pad(g[n].reshape(-1)[probes[n][1]], (0, B256_NSAMP - len(probes[n][1]))) for n in names])
+    fx["act_names"] = np.array(sorted(act_stats))
+    fx["act_negative"] = np.array([act_stats[k][0] for k in sorted(act_stats)], np.int64)
+    fx["act_near_zero"] = np.array([act_stats[k][1] for k in sorted(act_stats)], np.int64)
+    path = os.path.join(HERE, f"{B256_TAG}.npz")
+    np.savez_compressed(path, **fx)
+    print(B256_TAG, os.path.getsize(path), "bytes; loss", fx["scalars"][0], f"{time.time() - t0:.0f}s")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "b256":
+    make_b256()
