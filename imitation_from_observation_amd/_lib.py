@@ -12,6 +12,7 @@ CTX_VARIANT_REAL = 1
 CTX_VARIANT_INCEPTION2 = 2
 CTX_PREC_F32 = 0
 CTX_PREC_BF16X3 = 1
+CTX_DP_UNIQUE_ID_BYTES = 128
 
 
 class CtxConfig(ctypes.Structure):
@@ -74,6 +75,8 @@ SIGNATURES = {
     "ctx_train_step_u8": (_c.c_int, [_P, _U8, _U8, _U8, _c.c_int, _c.c_float, _F]),
     "ctx_demos_upload": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),
     "ctx_train_step_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _c.c_float, _F]),
+    "ctx_eval_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _F, _F, _F]),
+    "ctx_last_outputs": (_c.c_int, [_P, _F, _F, _F]),
     "ctx_eval": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _F, _F, _F]),
     "ctx_dev_forward_backward": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int]),
     "ctx_dev_forward": (_c.c_int, [_P, _P, _P, _P, _c.c_int]),
@@ -87,6 +90,12 @@ SIGNATURES = {
     "ctx_sync": (_c.c_int, [_P]),
     "ctx_dev_outputs": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P)]),
     "ctx_last_codes": (_c.c_int, [_P, _F, _F, _c.POINTER(_c.c_int)]),
+    "ctx_dp_unique_id": (_c.c_int, [_U8]),
+    "ctx_dp_init": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),
+    "ctx_dp_world": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),
+    "ctx_dp_allreduce_grads": (_c.c_int, [_P]),
+    "ctx_dp_train_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _F]),
+    "ctx_dp_scalars": (_c.c_int, [_P, _F]),
     "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
                                     _c.POINTER(_c.c_int)]),
     "ctx_debug_read": (_c.c_int, [_P, _c.c_char_p, _F, _c.c_size_t]),

@@ -15,6 +15,8 @@
 //   dZ      same rows for the code gradients
 //   one buffer per activation and per activation gradient (NHWC), sized for max_batch
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library itself is dlopen()ed by ctx_dp_init (no link-time dependency)
 
 #include <algorithm>
 #include <cmath>
@@ -107,6 +109,15 @@ struct ctx_handle {
     int* choice = nullptr;    // [2 * max_batch]: choicesrc | choicetgt
     float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
     int64_t slab_floats = 0;
+    // data parallel over RCCL (ctx_dp_*): communicator, a stream for the collectives (they overlap the encoders' backward),
+    // the events that order it with the compute stream, a device buffer for the global scalars
+    ncclComm_t dp_comm = nullptr;
+    int dp_rank = 0, dp_world = 1;
+    hipStream_t dp_stream = nullptr;
+    hipEvent_t dp_ev_ready = nullptr, dp_ev_done = nullptr;
+    float* dp_scal = nullptr;
+    bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
+    int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
 
     // per-op profiling (ctx_profile_step): HIP events around every launch group
     bool prof_on = false;
@@ -377,9 +388,15 @@ struct Side {
 constexpr int LANE_CTX = 0, LANE_DW = 1;
 
 // the tail of the gradient arena [first, Ppad) (translate/*, deconv/*: arena order is conv_context, conv, translate, deconv) is final
+void dp_reduce_range(ctx_handle* h, int64_t first, int64_t count);
 void fire_bucket(ctx_handle* h, int64_t first) {
-    if (!h->bucket_fn) return;
+    if (!h->bucket_fn && !h->dp_in_step) return;
     if (use_lanes(h)) join(h, LANE_DW);          // their filter / bias gradients ran on the side lane
+    if (h->dp_in_step) {                         // ctx_dp_train_step: the tail bucket goes out while the encoders' backward is enqueued
+        dp_reduce_range(h, first, h->Ppad - first);
+        h->dp_split = first;
+        return;
+    }
     h->bucket_fn(h->bucket_user, 0, first, h->Ppad - first);
 }
 
@@ -777,6 +794,82 @@ int upload_f32(ctx_handle* h, const float* src, const float* ctxf, const float* 
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// ================================================================================================
+// RCCL behind the C ABI (ctx_dp_init / ctx_dp_allreduce_grads).  The reference has no multi-GPU path; this is
+// the path's one exchange step (8e): SUM all-reduce of the flat f32 gradient arena between backward and Adam.  librccl is
+// dlopen()ed on first use -- in a process that already holds one (PyTorch ships its own librccl.so.1) the SAME copy is
+// shared, a plain C/C++ host gets the system's -- so libctxtrans.so keeps loading on boxes without RCCL.
+// ================================================================================================
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi& rccl() { static RcclApi api; return api; }
+
+bool rccl_load() {
+    RcclApi& a = rccl();
+    if (a.lib) return true;
+    std::vector<std::string> names;
+    if (const char* e = getenv("CTX_RCCL_LIB")) names.push_back(e);
+    names.insert(names.end(), {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"});
+    for (const std::string& n : names) {
+        a.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (a.lib) break;
+        a.err = dlerror();
+    }
+    if (!a.lib) return false;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p) { ok = false; a.err = std::string("missing symbol ") + n; } return p; };
+    a.GetUniqueId = (decltype(a.GetUniqueId))sym("ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))sym("ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))sym("ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))sym("ncclAllReduce");
+    a.Broadcast = (decltype(a.Broadcast))sym("ncclBroadcast");
+    a.GroupStart = (decltype(a.GroupStart))sym("ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))sym("ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(a.lib); a.lib = nullptr; }
+    return ok;
+}
+
+#define RCCL_TRY(h, expr)                                                                                   \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(h, CTX_E_DEVICE, "%s: %s", #expr, rccl().GetErrorString(r_));    \
+    } while (0)
+
+void dp_teardown(ctx_handle* h) {
+    if (h->dp_comm && rccl().lib) (void)rccl().CommDestroy(h->dp_comm);
+    h->dp_comm = nullptr;
+    if (h->dp_stream) { (void)hipStreamSynchronize(h->dp_stream); (void)hipStreamDestroy(h->dp_stream); h->dp_stream = nullptr; }
+    if (h->dp_ev_ready) { (void)hipEventDestroy(h->dp_ev_ready); h->dp_ev_ready = nullptr; }
+    if (h->dp_ev_done) { (void)hipEventDestroy(h->dp_ev_done); h->dp_ev_done = nullptr; }
+}
+
+// SUM all-reduce of grads[first, first + count) on the collective stream, ordered after everything the compute stream has
+// queued so far.  The compute stream is NOT made to wait here (dp_wait does that), so the collective overlaps what follows.
+void dp_reduce_range(ctx_handle* h, int64_t first, int64_t count) {
+    if (count <= 0) return;
+    float* g = h->arena + h->Ppad + first;
+    (void)hipEventRecord(h->dp_ev_ready, h->stream);
+    (void)hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0);
+    (void)rccl().AllReduce(g, g, (size_t)count, ncclFloat, ncclSum, h->dp_comm, h->dp_stream);
+}
+void dp_wait(ctx_handle* h) {
+    (void)hipEventRecord(h->dp_ev_done, h->dp_stream);
+    (void)hipStreamWaitEvent(h->stream, h->dp_ev_done, 0);
+}
+}  // namespace
+
 extern "C" {
 
 int ctx_abi_version(void) { return CTX_ABI_VERSION; }
@@ -895,6 +988,7 @@ void ctx_destroy(ctx_handle* h) {
     if (h->vdata) (void)hipFree(h->vdata);
     for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     delete h->gen;
+    dp_teardown(h);
     for (int l = 0; l < ctx_handle::NLANE; ++l) {
         if (h->aux[l]) { (void)hipStreamSynchronize(h->aux[l]); (void)hipStreamDestroy(h->aux[l]); }
         if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
@@ -1239,6 +1333,107 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
     return CTX_OK;
 }
 
+int ctx_dp_unique_id(uint8_t id[CTX_DP_UNIQUE_ID_BYTES]) {
+    if (!id) return fail(nullptr, CTX_E_INVALID, "id is NULL");
+    if (!rccl_load()) return fail(nullptr, CTX_E_DEVICE, "librccl could not be loaded: %s", rccl().err.c_str());
+    static_assert(sizeof(ncclUniqueId) == CTX_DP_UNIQUE_ID_BYTES, "unique-id blob size");
+    ncclUniqueId u;
+    ncclResult_t r = rccl().GetUniqueId(&u);
+    if (r != ncclSuccess) return fail(nullptr, CTX_E_DEVICE, "ncclGetUniqueId: %s", rccl().GetErrorString(r));
+    memcpy(id, &u, sizeof u);
+    return CTX_OK;
+}
+
+int ctx_dp_init(ctx_handle* h, const uint8_t id[CTX_DP_UNIQUE_ID_BYTES], int rank, int world) {
+    if (!h) return CTX_E_INVALID;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(h, CTX_E_INVALID, "bad rank %d / world %d", rank, world);
+    if (h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init was already called on this handle");
+    if (!rccl_load()) return fail(h, CTX_E_DEVICE, "librccl could not be loaded: %s", rccl().err.c_str());
+    HIP_TRY(h, hipSetDevice(h->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    RCCL_TRY(h, rccl().CommInitRank(&h->dp_comm, world, u, rank));
+    h->dp_rank = rank; h->dp_world = world;
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->dp_stream, hipStreamNonBlocking));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->dp_ev_ready, hipEventDisableTiming));
+    HIP_TRY(h, hipEventCreateWithFlags(&h->dp_ev_done, hipEventDisableTiming));
+    if (!h->dp_scal) TRY(dev_alloc(h, &h->dp_scal, 4));
+    // replicas start identical: rank 0's parameters and Adam slots (the step counter is host state: every rank must hold the
+    // same one, which ctx_init_params / ctx_set_adam_state guarantee when called alike)
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    RCCL_TRY(h, rccl().GroupStart());
+    for (int slot : {0, 2, 3}) {
+        float* p = h->arena + (int64_t)slot * h->Ppad;
+        RCCL_TRY(h, rccl().Broadcast(p, p, (size_t)h->Ppad, ncclFloat, 0, h->dp_comm, h->dp_stream));
+    }
+    RCCL_TRY(h, rccl().GroupEnd());
+    HIP_TRY(h, hipStreamSynchronize(h->dp_stream));
+    return CTX_OK;
+}
+
+int ctx_dp_world(const ctx_handle* h, int* rank, int* world) {
+    if (!h) return CTX_E_INVALID;
+    if (rank) *rank = h->dp_rank;
+    if (world) *world = h->dp_comm ? h->dp_world : 0;
+    return CTX_OK;
+}
+
+int ctx_dp_allreduce_grads(ctx_handle* h) {
+    if (!h) return CTX_E_INVALID;
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    if (!h->have_grads) return fail(h, CTX_E_STATE, "no backward has run");
+    HIP_TRY(h, hipSetDevice(h->device));
+    dp_reduce_range(h, 0, h->Ppad);
+    dp_wait(h);
+    HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr, float scalars[4]) {
+    TRY(check_B(h, B));
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    forward(h, B, MODE_TRAIN);
+    // two buckets: [split, Ppad) = translate/* + deconv/* leaves from inside backward (fire_bucket) and travels while the
+    // encoders' backward runs; [0, split) = the encoders after it.  simloss is a mean over the GLOBAL batch (arm_shaping.py:1345).
+    h->dp_in_step = true; h->dp_split = -1;
+    backward(h, B, B * h->dp_world);
+    h->dp_in_step = false;
+    const int64_t split = h->dp_split >= 0 ? h->dp_split : h->Ppad;
+    dp_reduce_range(h, 0, split);
+    dp_wait(h);
+    TRY(adam_step(h, lr));
+    h->last_B = B;
+    HIP_TRY(h, hipGetLastError());
+    if (scalars) return ctx_dp_scalars(h, scalars);
+    return CTX_OK;
+}
+
+int ctx_dp_scalars(ctx_handle* h, float scalars[4]) {
+    if (!h || !scalars) return CTX_E_INVALID;
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    // {loss, simloss, recon1, recon2} of this rank's shard -> global: recon sums add, simloss is the mean of equal shards
+    (void)hipEventRecord(h->dp_ev_ready, h->stream);
+    (void)hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0);
+    RCCL_TRY(h, rccl().AllReduce(h->scalars, h->dp_scal, 4, ncclFloat, ncclSum, h->dp_comm, h->dp_stream));
+    float s[4];
+    HIP_TRY(h, hipMemcpyAsync(s, h->dp_scal, sizeof s, hipMemcpyDeviceToHost, h->dp_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->dp_stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->dp_world > 1) {                         // (a one-rank sum is the identity: the device's own f64-accumulated loss stands)
+        s[1] /= (float)h->dp_world;
+        s[0] = (float)((double)s[1] + (double)s[2] + (double)s[3]);
+    }
+    memcpy(scalars, s, sizeof s);
+    return CTX_OK;
+}
+
 int ctx_demos_upload(ctx_handle* h, const uint8_t* vdata, int T, int N) {
     if (!h || !vdata || T <= 0 || N <= 0) return h ? fail(h, CTX_E_INVALID, "bad demo tensor") : CTX_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1273,6 +1468,38 @@ int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_
     TRY(adam_step(h, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+int ctx_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B, float scalars[4], float* out, float* out2) {
+    TRY(check_B(h, B));
+    if (!h->vdata) return fail(h, CTX_E_STATE, "ctx_demos_upload first");
+    if (!choicesrc || !choicetgt) return fail(h, CTX_E_INVALID, "NULL index array");
+    for (int b = 0; b < B; ++b)
+        if (choicesrc[b] < 0 || choicesrc[b] >= h->vN || choicetgt[b] < 0 || choicetgt[b] >= h->vN)
+            return fail(h, CTX_E_INVALID, "video index out of range [0,%d)", h->vN);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
+    forward(h, B, MODE_TRAIN);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
+    h->last_B = B;
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
+    return finish(h);
+}
+
+int ctx_last_outputs(ctx_handle* h, float* out, float* out2, float* tgt) {
+    if (!h) return CTX_E_INVALID;
+    if (h->last_B <= 0) return fail(h, CTX_E_STATE, "no training-mode forward has run");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)h->last_B * h->npi * sizeof(float);
+    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + (int64_t)h->last_B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (tgt) HIP_TRY(h, hipMemcpyAsync(tgt, h->img, bytes, hipMemcpyDeviceToHost, h->stream));   // img = [tgt | src | ctx]
     return finish(h);
 }
 

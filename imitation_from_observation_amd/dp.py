@@ -10,6 +10,10 @@ its simloss gradient by the GLOBAL batch (the `sim_batch` argument of ctx_dev_fo
 
 `DataParallelTrainer` only sequences an *engine* and the collective, so the same code runs on the
 HIP engine (cuda tensors, RCCL) and -- in the CPU test-suite -- on a gloo group with a stand-in engine.
+
+`RcclTrainer` is the same step with the collective INSIDE libctxtrans (ctx_dp_*: its own RCCL communicator, the
+two-bucket schedule on a second stream): torch.distributed is then needed only to ship the 128-byte rendezvous blob,
+and a host without torch can do that by any other means.
 """
 from __future__ import annotations
 
@@ -45,7 +49,7 @@ class HipEngine:
         self.n_params = self.translator.n_params
         self.params = self.arena[: self.stride]
         self.grads = self.arena[self.stride: 2 * self.stride]
-        self._scal = torch.zeros(4, device=self.dev, dtype=torch.float32)
+        self._scal_view = None
 
     @staticmethod
     def _ptr(t):
@@ -67,10 +71,15 @@ class HipEngine:
         self.translator.dev_adam(lr)
 
     def scalars_tensor(self):
-        """{loss, simloss, recon1, recon2} of the last forward as a device tensor."""
-        sc = self.translator.dev_scalars()       # synchronises the handle's stream
-        self._scal.copy_(torch.tensor([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]], dtype=torch.float32))
-        return self._scal
+        """{loss, simloss, recon1, recon2} of the last forward as a device tensor: a view of the f32[4] the loss kernel wrote
+        (ctx_dev_scalar_buf) -- stream-ordered with the step, no host round trip."""
+        if self._scal_view is None:
+            # zero-copy wrap of the device pointer through the CUDA array interface
+            holder = type("_DevArr", (), {"__cuda_array_interface__": {"shape": (4,), "typestr": "<f4", "version": 2,
+                                                                         "data": (self.translator.scalars_ptr, False)}})()
+            self._scal_view = torch.as_tensor(holder, device=self.dev)
+            self._scal_holder = holder
+        return self._scal_view
 
 
 class DataParallelTrainer:
@@ -131,3 +140,35 @@ class DataParallelTrainer:
             t[0] = t[1] + t[2] + t[3]
         v = [float(x) for x in t.cpu()]
         return dict(loss=v[0], simloss=v[1], recon1=v[2], recon2=v[3])
+
+
+class RcclTrainer:
+    """Data-parallel training with the exchange step inside libctxtrans (include/ctxtrans.h: ctx_dp_*).  One instance per
+    process / GPU.  `unique_id`: the blob from `Translator.dp_unique_id()` made on rank 0 -- when omitted and a
+    torch.distributed group is initialised it is broadcast through that group (any backend)."""
+
+    def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, seed=1234, rank=None, world=None,
+                 unique_id=None, precision=None):
+        if rank is None:
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        if world is None:
+            world = _world()
+        self.rank, self.world = rank, world
+        self.translator = Translator(H, W, df_dim, featsize, max_batch, device=device, precision=precision)
+        self.translator.init_params(seed)
+        self.n_params = self.translator.n_params
+        if unique_id is None:
+            unique_id = Translator.dp_unique_id() if rank == 0 else bytes(128)
+            if world > 1:
+                box = [unique_id]
+                dist.broadcast_object_list(box, src=0)
+                unique_id = box[0]
+        self.translator.dp_init(unique_id, rank, world)
+
+    def step(self, src, ctx, tgt, lr=1e-4, scalars=False):
+        """src / ctx / tgt: contiguous float32 cuda tensors [B,H,W,3] of this rank's shard (ready on the device: the library's
+        stream does not wait for torch's)."""
+        return self.translator.dp_train_step(HipEngine._ptr(src), HipEngine._ptr(ctx), HipEngine._ptr(tgt), src.shape[0], lr, scalars)
+
+    def scalars(self):
+        return self.translator.dp_scalars()

@@ -1,0 +1,186 @@
+"""Translator training loop: `ModelTrainer` of scripts/train_script.py:28-204 over the HIP translator.
+
+Same constructor arguments, same loop (`train_script.py:144-203`):
+  * demo tensor vdata[T, N, H, W, 3] split into the first `ntrain` videos (training) and the rest (validation); the first
+    200 training videos are written to `<basedir>vdata_train.npy` (:144-152);
+  * for itr in 1 .. nitr-1: choicesrc, choicetgt = np.random.choice(ntrain, batch_size) twice;
+    src[b] = traindata[b % nlen, choicesrc[b]], tgt[b] = traindata[b % nlen, choicetgt[b]], ctx[b] = traindata[0, choicetgt[b]];
+    one Adam(1e-4) step; every 4th iteration logs "itr loss sim r1 r2 err" (:153-167);
+  * every 40 iterations (and at every `save_every`) a validation batch sampled the same way from the held-out videos is
+    evaluated and logged with a trailing "E" (:169-178);
+  * every `save_every` iterations a checkpoint `<basedir><itr>/model_<itr>_<loss>_<r1>_<r2>_<err>` and `validloss.npy` are
+    written, plus -- not for the Inception variant -- ten (translation, reconstruction) clips of single video pairs (:179-195);
+  * from `save_every` on, every validation appends a row Iteration, Loss, Sim, R1, R2, NNErr to the tabular log (:196-203).
+
+What differs, and why:
+  * the mp4 -> vdata step (:59-96) needs imageio/ffmpeg and scipy.misc.imresize, neither present: the demo tensor comes
+    in as an array or a `.npy` path (the file the reference itself saves);
+  * the sess.run calls are `Translator.train_step_sampled` / `eval_sampled` on the demo tensor resident in HBM (uint8;
+    `gather_triples_kernel` builds the batch with the trainer's x / 127.5 - 1 scaling) when the float demo tensor lies
+    exactly on that uint8 lattice -- bit-identical to feeding the host-gathered float batch -- and
+    `train_step` / `evaluate` on the host-gathered batch otherwise;
+  * `nn_err` (:148) reads `featreshape`, which only exists in the Inception branch (NameError for the other
+    models).  Its intended meaning -- for every output j the index of the nearest tgt frame, compared with j % nlen -- is
+    computed on the host from `out` and the tgt slot for every model;
+  * clips are stored as uint8 arrays `__<k>trans.npy` / `__<k>recon.npy` (imageio absent), same frames the gifs would hold;
+  * the tabular log is a CSV `<basedir>progress.csv` (rllab's logger is outside the hot path).
+Random draws come from the global `np.random` in the reference's order, so a seeded run samples the same batches.
+"""
+from __future__ import annotations
+
+import csv
+import os
+
+import numpy as np
+
+LEARNING_RATE = 1e-4          # fed at every step, train_script.py:163,167
+
+
+def nn_err(tgt, out, nlen):
+    """train_script.py:148 with featreshape[2] = the tgt slot:
+    sum_j | argmin_i mean((tgt_i - out_j)^2) - (j % nlen) |."""
+    B = len(out)
+    a = np.asarray(tgt, np.float64).reshape(B, -1)
+    b = np.asarray(out, np.float64).reshape(B, -1)
+    # mean((a_i - b_j)^2) = (|a_i|^2 + |b_j|^2 - 2 a_i.b_j) / n
+    d = (a * a).sum(1)[:, None] + (b * b).sum(1)[None, :] - 2.0 * (a @ b.T)
+    return int(np.abs(np.argmin(d, axis=0) - np.arange(B) % nlen).sum())
+
+
+def on_u8_lattice(vdata):
+    """(uint8 tensor, True) when the float demo tensor is exactly what transform() makes of uint8 frames
+    (k / 127.5 - 1, train_script.py:16-19), else (None, False)."""
+    v = np.asarray(vdata)
+    if v.dtype == np.uint8:
+        return v, True
+    k = np.rint((v.astype(np.float64) + 1.0) * 127.5)
+    if k.min() < 0 or k.max() > 255 or np.abs(k / 127.5 - 1.0 - v).max() > 1e-6:
+        return None, False
+    return k.astype(np.uint8), True
+
+
+class ModelTrainer:
+    MODELS = {"ContextSkipNew": "skipnew", "ContextAEReal": "real", "ContextAEInception": "inception2"}
+
+    def __init__(self, idims, nvideos, ntrain, batch_size, model, nitr, save_every, nlen, nskip, rescale=True, inception=False,
+                 strides=None, kernels=None, filters=None, *, vdata=None, basedir="model/", device=0, seed=0, translator=None,
+                 precision=None, log=print):
+        """The reference's 14 positional arguments (train_script.py:29-30; the launchers omit the last five, SURVEY.md 3.4-b,
+        hence the defaults), then: vdata (array or .npy path of the demo tensor), basedir (logger._snapshot_dir), device,
+        seed of the parameter initialiser, an optional ready-made translator (tests), the arithmetic, the log sink."""
+        if model not in self.MODELS:
+            raise ValueError(f"model must be one of {sorted(self.MODELS)}")
+        self.idims, self.nvideos, self.ntrain, self.batch_size = tuple(idims), nvideos, ntrain, batch_size
+        self.model, self.nitr, self.save_every, self.nlen, self.nskip = model, nitr, save_every, nlen, nskip
+        self.rescale, self.inception = rescale, inception
+        self.strides, self.kernels, self.filters = strides, kernels, filters
+        self.vdata, self.basedir, self.device, self.seed = vdata, basedir, device, seed
+        self.translator, self.precision, self.log = translator, precision, log
+        self.allloss, self.validloss = [], []
+
+    # ------------------------------------------------------------------ the model behind the four sess.run sites
+    def _build(self):
+        if self.translator is not None:
+            return self.translator
+        from .translator import Translator
+        H, W = self.idims
+        if self.inception:
+            from .oursinception import InceptionTranslator
+            tr = InceptionTranslator((H, W), max_batch=self.batch_size, device=self.device, precision=self.precision)
+            tr.tr.init_params(self.seed)
+            return tr
+        variant = self.MODELS[self.model]
+        tr = Translator(H, W, featsize=100 if variant == "real" else 1024, max_batch=self.batch_size, device=self.device,
+                        variant=variant, precision=self.precision)
+        tr.init_params(self.seed)                                  # tf.global_variables_initializer, train_script.py:129
+        return tr
+
+    def _batch(self, data, choicesrc, choicetgt):
+        ar = np.arange(0, self.batch_size) % self.nlen
+        return data[ar, choicesrc], data[0, choicetgt], data[ar, choicetgt]          # srcdata, tgtctx, tgtdata (:156-159)
+
+    def train(self):
+        basedir = self.basedir if self.basedir.endswith("/") else self.basedir + "/"
+        os.makedirs(basedir, exist_ok=True)
+        vdata = np.load(self.vdata) if isinstance(self.vdata, (str, os.PathLike)) else np.asarray(self.vdata)
+        if vdata.ndim != 5 or vdata.shape[2:4] != self.idims or vdata.shape[0] < self.nlen:
+            raise ValueError(f"vdata must be [T >= {self.nlen}, N, {self.idims[0]}, {self.idims[1]}, 3], got {vdata.shape}")
+        log, B, nlen = self.log, self.batch_size, self.nlen
+        log(str(vdata.shape))
+        tr = self._build()
+        n = vdata.shape[1]
+        ntrain = self.ntrain
+        nvalid = n - ntrain
+        if ntrain <= 0 or nvalid <= 0:
+            raise ValueError(f"ntrain = {ntrain} of {n} videos leaves no training / validation split")
+        log("%s %s" % (ntrain, nvalid))
+        validdata = vdata[:, ntrain:]
+        traindata = vdata[:, :ntrain]
+        log(str(validdata.shape) + str(traindata.shape))
+        np.save(basedir + "vdata_train", traindata[:, :200])
+        # device-resident demo tensor + device sampler where that is bit-identical to the host gather
+        u8, lattice = on_u8_lattice(vdata) if not self.inception else (None, False)
+        resident = lattice and hasattr(tr, "load_demos")
+        if resident:
+            tr.load_demos(u8)
+
+        def train_step(cs, ct):
+            if resident:
+                return tr.train_step_sampled(cs, ct, lr=LEARNING_RATE)
+            src, ctx, tgt = self._batch(traindata, cs, ct)
+            if self.inception:
+                return tr.train_step_u8(src, ctx, tgt, lr=LEARNING_RATE)
+            return tr.train_step(src, ctx, tgt, lr=LEARNING_RATE)
+
+        def evaluate(cs, ct):
+            """loss, sim, r1, r2, out, out2, tgt of a validation batch (indices into validdata)."""
+            src, ctx, tgt = self._batch(validdata, cs, ct)
+            if resident:
+                ev = tr.eval_sampled(np.asarray(cs) + ntrain, np.asarray(ct) + ntrain)
+            elif self.inception:
+                f = tr.front.features(np.concatenate([src, ctx, tgt]))
+                src, ctx, tgt = f[:B], f[B:2 * B], f[2 * B:]
+                ev = tr.tr.evaluate(src, ctx, tgt)
+            else:
+                ev = tr.evaluate(src, ctx, tgt)
+            return ev, tgt
+
+        core = getattr(tr, "tr", tr)                               # the Translator inside an InceptionTranslator
+        rows = []
+        for itr in range(1, self.nitr):
+            choicesrc = np.random.choice(ntrain, B)
+            choicetgt = np.random.choice(ntrain, B)
+            sc = train_step(choicesrc, choicetgt)
+            if itr % 4 == 0:
+                out, _, tgt = core.last_outputs(out=True, tgt=True)
+                err = nn_err(tgt, out, nlen)
+                log("%s %s %s %s %s %s" % (itr, sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"], err))
+                self.allloss.append(sc["loss"])
+            if itr % 40 == 0 or itr % self.save_every == 0:
+                choicesrc = np.random.choice(nvalid, B)
+                choicetgt = np.random.choice(nvalid, B)
+                ev, tgt = evaluate(choicesrc, choicetgt)
+                loss, sim, r1, r2 = ev["loss"], ev["simloss"], ev["recon1"], ev["recon2"]
+                err = nn_err(tgt, ev["out"], nlen)
+                log("%s %s %s %s %s %s E" % (itr, loss, sim, r1, r2, err))
+                self.validloss.append(loss)
+                if itr % self.save_every == 0:
+                    os.mkdir(basedir + str(itr))
+                    core.save("%s%d/model_%d_%.2f_%.2f_%.2f_%d" % (basedir, itr, itr, loss, r1, r2, err), prefix="contextmodel/")
+                    np.save("%s%d/validloss" % (basedir, itr), self.validloss)
+                    if not self.inception:
+                        for kk in range(10):
+                            choicesrc = [np.random.randint(nvalid)] * B
+                            choicetgt = [np.random.randint(nvalid)] * B
+                            clip, _ = evaluate(choicesrc, choicetgt)
+                            for tag, frames in (("trans", clip["out"]), ("recon", clip["out2"])):
+                                u = (np.clip((frames[:nlen] + 1.0) / 2.0, 0, 1) * 255).astype(np.uint8)     # savegif's frames (:23-26)
+                                np.save("%s%d/__%d%s" % (basedir, itr, kk, tag), u)
+                if itr >= self.save_every:
+                    rows.append(dict(Iteration=itr, Loss=loss, Sim=sim, R1=r1, R2=r2, NNErr=err))
+                    with open(basedir + "progress.csv", "w", newline="") as f:
+                        w = csv.DictWriter(f, fieldnames=["Iteration", "Loss", "Sim", "R1", "R2", "NNErr"])
+                        w.writeheader()
+                        w.writerows(rows)
+        self.translator = tr
+        return tr

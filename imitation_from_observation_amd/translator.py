@@ -289,6 +289,34 @@ class Translator:
         self._ck(self._lib.ctx_train_step_sampled(self._h, cs.ctypes.data_as(ip), ct.ctypes.data_as(ip), cs.size, float(lr), _fp(sc)))
         return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
+    def eval_sampled(self, choicesrc, choicetgt, outputs=True):
+        """Forward + losses on the batch sampled from the resident demo tensor (the trainer's validation fetch,
+        train_script.py:169-176); no update."""
+        cs = np.ascontiguousarray(choicesrc, dtype=np.int32)
+        ct = np.ascontiguousarray(choicetgt, dtype=np.int32)
+        if cs.shape != ct.shape or cs.ndim != 1:
+            raise ValueError("choicesrc / choicetgt must be 1-D and equally long")
+        B = cs.size
+        sc = np.empty(4, np.float32)
+        out = np.empty((B, self.H, self.W, self.C), np.float32) if outputs else None
+        out2 = np.empty((B, self.H, self.W, self.C), np.float32) if outputs else None
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._ck(self._lib.ctx_eval_sampled(self._h, cs.ctypes.data_as(ip), ct.ctypes.data_as(ip), B, _fp(sc),
+                                            _fp(out) if outputs else None, _fp(out2) if outputs else None))
+        res = dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+        if outputs:
+            res["out"], res["out2"] = out, out2
+        return res
+
+    def last_outputs(self, out=True, out2=False, tgt=False):
+        """Host copies of (out, out2, tgt frames) of the last training-mode forward; None where not asked for."""
+        B = ctypes.c_int()
+        self._ck(self._lib.ctx_last_codes(self._h, None, None, ctypes.byref(B)))
+        shp = (B.value, self.H, self.W, self.C)
+        arrs = [np.empty(shp, np.float32) if w else None for w in (out, out2, tgt)]
+        self._ck(self._lib.ctx_last_outputs(self._h, *[_fp(a) if a is not None else None for a in arrs]))
+        return tuple(arrs)
+
     def evaluate(self, src, ctx, tgt, outputs=True):
         """Forward + losses (train_script.py:176,192-193)."""
         src, ctx, tgt, B = self._triple(src, ctx, tgt)
@@ -331,6 +359,44 @@ class Translator:
 
     def sync(self):
         self._ck(self._lib.ctx_sync(self._h))
+
+    # ------------------------------------------------------------------ data parallel over RCCL, behind the C ABI
+    @staticmethod
+    def dp_unique_id():
+        """The rendezvous blob rank 0 makes (an ncclUniqueId, 128 bytes); ship it to the other ranks, then dp_init everywhere."""
+        lib = _lib.load()
+        buf = (ctypes.c_uint8 * _lib.CTX_DP_UNIQUE_ID_BYTES)()
+        rc = lib.ctx_dp_unique_id(buf)
+        if rc != _lib.CTX_OK:
+            msg = lib.ctx_last_error(None)
+            raise CtxError(rc, msg.decode() if msg else "")
+        return bytes(buf)
+
+    def dp_init(self, unique_id, rank, world):
+        """Collective: RCCL communicator on this handle's device; rank 0's parameters and Adam slots are broadcast."""
+        if len(unique_id) != _lib.CTX_DP_UNIQUE_ID_BYTES:
+            raise ValueError(f"unique_id must be {_lib.CTX_DP_UNIQUE_ID_BYTES} bytes")
+        buf = (ctypes.c_uint8 * _lib.CTX_DP_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self._lib.ctx_dp_init(self._h, buf, int(rank), int(world)))
+
+    def dp_allreduce_grads(self):
+        """In-place SUM all-reduce of the gradient arena, stream-ordered after the backward pass (asynchronous)."""
+        self._ck(self._lib.ctx_dp_allreduce_grads(self._h))
+
+    def dp_train_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4, scalars=False):
+        """One data-parallel step on this rank's shard (device addresses of f32 [B,H,W,3]): forward, backward with the simloss
+        mean over the global batch, two-bucket all-reduce overlapped with the encoders' backward, Adam.  scalars=True also
+        returns the GLOBAL dict(loss, simloss, recon1, recon2) (one more tiny collective + a sync)."""
+        sc = np.empty(4, np.float32) if scalars else None
+        self._ck(self._lib.ctx_dp_train_step(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt), B,
+                                             float(lr), _fp(sc) if scalars else None))
+        if scalars:
+            return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
+    def dp_scalars(self):
+        sc = np.empty(4, np.float32)
+        self._ck(self._lib.ctx_dp_scalars(self._h, _fp(sc)))
+        return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
     @property
     def stream_ptr(self):

@@ -21,6 +21,7 @@
  *   ctx_dev_*             the same train step split into device-resident phases so a host can put
  *                         an RCCL gradient all-reduce between backward and Adam (new: the
  *                         reference has no multi-GPU path)
+ *   ctx_dp_*              that all-reduce itself, on RCCL, behind this ABI (no torch needed)
  *
  * Conventions: every function returns 0 on success or a negative CTX_E_* code; the message is
  * available from ctx_last_error().  No C++ exception crosses the ABI.  Host buffers are caller
@@ -144,6 +145,13 @@ int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx, con
 int ctx_demos_upload(ctx_handle* h, const uint8_t* vdata, int T, int N);
 int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B,
                            float lr, float scalars[4]);
+/* The validation batch of the trainer (train_script.py:169-176) from the resident demo tensor: the same gather as
+ * ctx_train_step_sampled, forward + losses, no update.  out / out2 (nullable) [B,H,W,3]. */
+int ctx_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B, float scalars[4],
+                     float* out, float* out2);
+/* Host copies of model.out / model.out2 [B,H,W,3] of the last training-mode forward and of the tgt frames it was fed
+ * (tfinput[2]) -- what the trainer's `nn_err` fetch reads next to the optimizer (train_script.py:148,163).  Any may be NULL. */
+int ctx_last_outputs(ctx_handle* h, float* out, float* out2, float* tgt);
 /* Forward + losses only.  out / out2 (nullable) [B,H,W,3]. */
 int ctx_eval(ctx_handle* h, const float* src, const float* ctx, const float* tgt, int B,
              float scalars[4], float* out, float* out2);
@@ -182,6 +190,30 @@ int ctx_dev_outputs(ctx_handle* h, const float** out, const float** out2, const 
  * losses; rows are de-padded (the device keeps them at a stride of featsize rounded up to 32 for CTX_VARIANT_REAL).
  * Either pointer may be NULL; *B (nullable) receives the batch of that forward. */
 int ctx_last_codes(ctx_handle* h, float* input_z, float* translated_z, int* B);
+
+/* ---- data parallel over RCCL (new: the reference is single-device) ------------------------------
+ * One process per GPU, each with a full replica + Adam state; per step: local forward/backward on the rank's shard with
+ * the simloss mean taken over the GLOBAL batch -> SUM all-reduce of the flat f32 gradient arena over xGMI -> identical
+ * local Adam.  librccl is loaded at run time on the first ctx_dp_* call (CTX_RCCL_LIB overrides the search; a process
+ * that already holds a librccl.so.1 -- PyTorch's -- shares it).
+ *   ctx_dp_unique_id      rank 0 makes the rendezvous blob (an ncclUniqueId); the host ships it to the other ranks
+ *   ctx_dp_init           collective: creates the communicator on the handle's device, then broadcasts rank 0's parameters
+ *                         and Adam slots so the replicas start identical
+ *   ctx_dp_allreduce_grads  the exchange step alone: in-place SUM all-reduce of the gradient arena, stream-ordered between
+ *                         ctx_dev_forward_backward(sim_batch = B * world) and ctx_dev_adam (asynchronous)
+ *   ctx_dp_train_step     the whole step with the two-bucket schedule: the translate/deconv gradients are reduced on a second
+ *                         stream while the encoders' backward runs, the encoders' after it; then Adam.  scalars (nullable) =
+ *                         GLOBAL {loss, simloss, recon1, recon2} (one more 16-byte all-reduce and a sync).  d_* are DEVICE
+ *                         pointers [B,H,W,3] f32; every rank passes the same B.
+ *   ctx_dp_scalars        global scalars of the last forward (collective) */
+#define CTX_DP_UNIQUE_ID_BYTES 128
+int ctx_dp_unique_id(uint8_t id[CTX_DP_UNIQUE_ID_BYTES]);
+int ctx_dp_init(ctx_handle* h, const uint8_t id[CTX_DP_UNIQUE_ID_BYTES], int rank, int world);
+int ctx_dp_world(const ctx_handle* h, int* rank, int* world);   /* world = 0 before ctx_dp_init */
+int ctx_dp_allreduce_grads(ctx_handle* h);
+int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr,
+                      float scalars[4]);
+int ctx_dp_scalars(ctx_handle* h, float scalars[4]);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* One entry per launch group of a train step (a layer's forward, input gradient, filter gradient,

@@ -53,3 +53,44 @@ def test_overlapped_allreduce_path_equals_plain_path(monkeypatch):
         assert first == info["translate/trans_h0/Matrix"] and first + count >= max(info.values())
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_behind_the_c_abi_on_one_rank():
+    """ctx_dp_* (SURVEY.md 8b): the library's own RCCL communicator.  On a one-rank communicator the SUM is the identity, so
+    the two-bucket overlapped step (ctx_dp_train_step) and the phase form (ctx_dev_forward_backward -> ctx_dp_allreduce_grads
+    -> ctx_dev_adam) must leave bit-for-bit the parameters and scalars of ctx_train_step; ctx_dp_init's broadcast must keep
+    rank 0's parameters."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import CtxError, Translator
+    from imitation_from_observation_amd.dp import RcclTrainer
+    H, W, d, F, B = 32, 32, 32, 128, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    fr = [(torch.rand((B, H, W, 3), device="cuda", generator=g) * 2 - 1).contiguous() for _ in range(3)]
+    torch.cuda.synchronize()
+    host = [x.cpu().numpy() for x in fr]
+    uid = Translator.dp_unique_id()
+    assert len(uid) == 128 and any(uid)
+    tr = RcclTrainer(H, W, d, F, max_batch=B, device=0, seed=21, rank=0, world=1, unique_id=uid)
+    with Translator(H, W, d, F, max_batch=B) as ref, Translator(H, W, d, F, max_batch=B) as ph:
+        p0 = tr.translator.get_params_flat()
+        assert np.abs(p0).max() > 0                                   # the broadcast kept rank 0's parameters
+        ref.set_params_flat(p0)
+        ph.set_params_flat(p0)
+        with pytest.raises(CtxError):
+            ph.dp_allreduce_grads()                                   # no communicator on this handle yet
+        ph.dp_init(Translator.dp_unique_id(), 0, 1)
+        with pytest.raises(CtxError):
+            ph.dp_init(uid, 0, 1)                                     # twice
+        for it in range(3):
+            sc = tr.step(*fr, lr=1e-3, scalars=True)
+            sref = ref.train_step(*host, lr=1e-3)
+            assert sc == sref, it
+            ph.dev_forward_backward(fr[0].data_ptr(), fr[1].data_ptr(), fr[2].data_ptr(), B, sim_batch=B)
+            ph.dp_allreduce_grads()
+            ph.dev_adam(1e-3)
+            assert ph.dp_scalars() == sref
+        np.testing.assert_array_equal(tr.translator.get_params_flat(), ref.get_params_flat())
+        np.testing.assert_array_equal(ph.get_params_flat(), ref.get_params_flat())
+    tr.translator.close()
