@@ -1,0 +1,335 @@
+// dconv.h -- direct convolutions for NARROW channel counts (3 ... 64 per pixel): ContextAEReal's layers (filters 32/16/16/8,
+// gym/envs/mujoco/arm_shaping.py:1622-1629, 1659-1672) and the 3-channel edge layers of ContextSkipNew (h0_conv :1283, the
+// input gradient of d_h4 :1329).
+//
+// Why not the implicit GEMM of igemm.h: with <= 32 channels per tap every 16-byte gather feeds a single 32-column MFMA
+// block, so a tile is fed from L2 at ~20 B/clk/CU and the matrix pipe idles at 50 % (measured: ContextAEReal 0.18 of its
+// roofline).  Here a block stages the INPUT HALO TILE of its output tile in LDS once (coalesced NHWC rows, zero outside the
+// image) and walks the 25 taps over it: every input element is fetched from HBM/L2 once per tile instead of once per tap,
+// and the operands of v_mfma_f32_16x16x4_f32 (16-wide tiles: no padding of 16-channel layers to 32) come out of LDS with
+// one ds_read_b128 per four MFMAs.
+//
+//   dconv_fwd    out[p][n] = epilogue( sum_taps sum_k in[S*p + tap][k] * w[tap][k][n] )      k = channel
+//                one kernel for  conv2d stride 1 / 2  (= input gradient of conv2d_transpose),
+//                                conv2d_transpose stride 1 (flipped taps) and stride 2 (four output parity classes, each
+//                                with its own tap subset over the SMALL grid)  (= input gradient of conv2d)
+//   dconv_wgrad  dw[tap][a][b] = sum_pixels big[S*p + tap][a] * small[p][b]                 k = pixel
+//                rows m = tap * CA + a packed densely (cin = 3: 75 rows, not 25 x 32), persistent blocks that keep their
+//                partial sums in registers over all their tiles, fixed-order slab reduction (deterministic, no atomics)
+//
+// K order inside a 16-wide MFMA step: lane (row = l & 15, kg = l >> 4) supplies k = 16*chunk + 4*kg + t to step t -- the
+// same permutation for A and B, so one float4 per operand feeds four MFMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm.h"
+
+namespace ctx {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DC_MAXTAPS = 25;
+constexpr int DC_THREADS = 512;          // 8 waves: one or two 16-row blocks each
+constexpr int DC_NW = DC_THREADS / 64;
+
+struct DcTap { int16_t dy, dx, wt, pad; };        // input-tile pixel offset of the tap; filter tap index ky * 5 + kx
+struct DcClass { int tap0, ntaps, oy, ox; };       // taps [tap0, tap0 + ntaps); physical output pixel = (osc*y + oy, osc*x + ox)
+
+struct DcFwd {
+    const float* x1; int ld1; int c1;              // input channels [0, c1)
+    const float* x2; int ld2; int nmod2;           // input channels [c1, CI): tensor 2, image index img % nmod2 (the ctx skip)
+    int CI;                                        // c1 + c2 : 3, or a multiple of 8 up to 64
+    int hin, win, nimg;
+    int S;                                         // input pixels per logical output pixel (1 | 2)
+    int y_org, x_org;                              // input pixel of logical output (0,0) at tap offset (0,0)
+    int hlog, wlog;                                // logical output grid = the GEMM's row space (transposed stride 2: the small grid)
+    int TH, TW;                                    // tile of logical outputs, TH * TW = 16 * DC_NW * MI
+    int IH, IW;                                    // input tile incl. halo
+    const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
+    int N;                                         // real output channels (<= 16 * NB)
+    int GT;                                        // taps staged in LDS per pass
+    int ncls; DcClass cls[4]; DcTap taps[DC_MAXTAPS];
+    int osc, hout, wout;                           // physical output grid
+    int tiles_y, tiles_x;
+    Epi ep;
+};
+
+__host__ __device__ inline int dc_cip(int cik) { return cik + 4 - (cik == 4 ? 4 : 0); }      // LDS pixel stride: CIK + 4 (bank spread), 4 for the 3-channel tile
+
+// LDS: tile[IH*IW][CIP] | W4[GTK/4][NP][4] | toff[GTP]     (GTK = staged taps (padded to whole 16-k chunks) * CIK)
+template <int CIK, int MI, int NB>
+__global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
+    constexpr int CIP = CIK == 4 ? 4 : CIK + 4;
+    constexpr int NP = NB * 16;
+    constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;          // taps per 16-k chunk
+    constexpr int CPT = CIK >= 16 ? CIK / 16 : 1;          // chunks per tap
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    float* tile = smem;
+    const int tile_floats = (P.IH * P.IW * CIP + 3) & ~3;
+    float* W4 = smem + tile_floats;
+    const int gtp = (P.GT + TPC - 1) / TPC * TPC;           // staged tap slots (whole chunks)
+    int* toff = reinterpret_cast<int*>(W4 + gtp * CIK * NP);
+
+    int b = blockIdx.x;
+    const int txi = b % P.tiles_x; b /= P.tiles_x;
+    const int tyi = b % P.tiles_y;
+    const int img = b / P.tiles_y;
+    const int ty0 = tyi * P.TH, tx0 = txi * P.TW;
+    const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
+
+    // ---- input halo tile -> LDS (zero outside the image)
+    if constexpr (CIK == 4) {
+        const float* src = P.x1 + (int64_t)img * P.hin * P.win * 3;
+        const int rowf = P.IW * 3;
+        for (int i = tid; i < P.IH * rowf; i += DC_THREADS) {
+            const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            float v = 0.f;
+            if ((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win) v = src[((int64_t)gy * P.win + gx) * 3 + ch];
+            tile[(iy * P.IW + ix) * 4 + ch] = v;
+        }
+        for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) tile[i * 4 + 3] = 0.f;
+    } else {
+        constexpr int C4 = CIK / 4;
+        const float* s1 = P.x1 + (int64_t)img * P.hin * P.win * P.ld1;
+        const float* s2 = P.x2 ? P.x2 + (int64_t)(img % P.nmod2) * P.hin * P.win * P.ld2 : nullptr;
+        for (int i = tid; i < P.IH * P.IW * C4; i += DC_THREADS) {
+            const int pi = i / C4, c = (i - pi * C4) * 4;
+            const int iy = pi / P.IW, ix = pi - iy * P.IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            float4 v = zero4();
+            if ((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win) {
+                const int64_t pix = (int64_t)gy * P.win + gx;
+                v = c < P.c1 ? ldg4(s1 + pix * P.ld1 + c) : ldg4(s2 + pix * P.ld2 + (c - P.c1));
+            }
+            *reinterpret_cast<float4*>(&tile[pi * CIP + c]) = v;
+        }
+    }
+
+    // this wave's rows: row block rb = wv * MI + mi -> logical pixel (ty, tx0l + l15)
+    const int rbw = P.TW >> 4;                               // row blocks per tile row
+    const int nrb = P.TH * rbw;                              // row blocks of the tile (<= DC_NW * MI; the other waves only keep the barriers)
+    int abase[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int rb = wv * MI + mi, ty = rb / rbw, tx = (rb - ty * rbw) * 16 + l15;
+        abase[mi] = rb < nrb ? ((P.S * ty) * P.IW + P.S * tx) * CIP : 0;
+    }
+    const bool active = wv * MI < nrb;
+
+    for (int ci = 0; ci < P.ncls; ++ci) {
+        const DcClass cl = P.cls[ci];
+        f32x4 acc[MI][NB];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int t0 = 0; t0 < cl.ntaps; t0 += P.GT) {
+            const int nt = cl.ntaps - t0 < P.GT ? cl.ntaps - t0 : P.GT;
+            const int ntp = (nt + TPC - 1) / TPC * TPC;
+            __syncthreads();                                 // tile complete / previous stage consumed
+            // ---- stage the filter taps [t0, t0 + nt) of this class: W4[(e*CIK + k) / 4][n][k & 3]
+            for (int i = tid; i < ntp * CIK * NP; i += DC_THREADS) {
+                const int n = i % NP, ek = i / NP, e = ek / CIK, k = ek - e * CIK;
+                float v = 0.f;
+                if (e < nt && n < P.N && k < P.CI) {
+                    const int wt = P.taps[cl.tap0 + t0 + e].wt;
+                    v = P.wmode ? P.w[((int64_t)wt * P.N + n) * P.CI + k] : P.w[((int64_t)wt * P.CI + k) * P.N + n];
+                }
+                W4[((ek >> 2) * NP + n) * 4 + (ek & 3)] = v;
+            }
+            for (int e = tid; e < ntp; e += DC_THREADS) {
+                const DcTap tp = P.taps[cl.tap0 + t0 + (e < nt ? e : 0)];
+                toff[e] = (tp.dy * P.IW + tp.dx) * CIP;
+            }
+            __syncthreads();
+
+            const int nchunks = active ? ntp / TPC * CPT : 0;
+            for (int c = 0; c < nchunks; ++c) {
+                const int k16 = 16 * c + 4 * kg;              // this lane's first k of the chunk, in staged-K coordinates
+                const int e = k16 / CIK, kin = k16 - e * CIK;
+                const int to = toff[e] + kin;
+                float4 a4[MI], b4[NB];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const float4*>(&tile[abase[mi] + to]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const float4*>(&W4[((4 * c + kg) * NP + nb * 16 + l15) * 4]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float av = t == 0 ? a4[mi].x : t == 1 ? a4[mi].y : t == 2 ? a4[mi].z : a4[mi].w;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const float bv = t == 0 ? b4[nb].x : t == 1 ? b4[nb].y : t == 2 ? b4[nb].z : b4[nb].w;
+                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- epilogue of this class.  D: col = l15, row = 4 * kg + r
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int rb = wv * MI + mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
+            const int y = ty0 + ty;
+            if (rb >= nrb || y >= P.hlog) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = tx0 + txb + 4 * kg + r;
+                if (x >= P.wlog) continue;
+                const int64_t pix = ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * x + cl.ox);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int n = nb * 16 + l15;
+                    if (n < P.N) epi_store(P.ep, 0, pix, n, acc[mi][nb][r]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Filter gradient.  dw[tap][a][b] = sum over images and small-grid pixels p of big[S*p + tap - pad][a] * small[p][b].
+// GEMM rows m = tap * CA + a (M = 25 * CA, dense), columns b, K = pixels.  A block stages the small tile and the big halo
+// tile of one (image, tile) in LDS, runs all its row blocks over the tile's pixels, moves to its next tile (persistent,
+// accumulators stay in registers) and finally writes ONE partial [M][CB] to its slab; dconv_wgrad_reduce adds the slabs.
+// ------------------------------------------------------------------------------------------------
+struct DcWgrad {
+    const float* big; int ldb; int CA;              // big-grid tensor (channels a); CA == 3: read as [pixel][3]
+    const float* s1; int ld1; int c1;              // small-grid tensor, channels [0, c1)
+    const float* s2; int ld2; int nmod2;           // channels [c1, CB) from tensor 2 (ctx skip, image % nmod2)
+    int CB;                                        // c1 + c2, a multiple of 8
+    int hb, wb, hs, ws, nimg;
+    int S, pad;
+    int TH, TW, tw_sh;                             // small-grid tile, TW = 1 << tw_sh in {16, 32, 64}, so TH*TW is a multiple of 16
+    int IH, IW;                                    // big tile incl. halo: S*(TH-1)+5, S*(TW-1)+5
+    int tiles_y, tiles_x, ntiles;                  // per image; ntiles = nimg * tiles_y * tiles_x
+    int M;                                         // 25 * CA
+    int RBW;                                       // row blocks (of 16 rows of M) per wave
+    float* slab;                                   // [gridDim.x][M][CBP]
+    float* out;                                    // dw [25][CA][CB]
+};
+
+template <int CAK /* big-tile pixel stride class: 4 (CA = 3), 8, 16, 32 */, int RBW, int NB>
+__global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P) {
+    constexpr int CAP = CAK == 4 ? 4 : CAK + 4;             // pixel strides = 4 mod 16 dwords: the four pixel groups (kg) of a wave read
+    constexpr int NP = NB * 16;                             // 16-bank windows that do not overlap (4 pixels * stride = 16 mod 64)
+    constexpr int CBP = NP + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    float* bigt = smem;                                      // [IH*IW][CAP]
+    float* smallt = smem + ((P.IH * P.IW * CAP + 3) & ~3);   // [TH*TW][CBP]
+    const int npix = P.TH * P.TW;
+
+    // this lane's A rows: m = (wv * RBW + rb) * 16 + l15 -> (tap, a) -> offset of the tap inside the big tile + channel
+    int aoff[RBW];
+    bool aok[RBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb) {
+        const int m = (wv * RBW + rb) * 16 + l15;
+        aok[rb] = m < P.M;
+        const int mm = aok[rb] ? m : 0;
+        const int tap = mm / P.CA, a = mm - tap * P.CA, ky = tap / 5, kx = tap - 5 * ky;
+        aoff[rb] = (ky * P.IW + kx) * CAP + a;
+    }
+    f32x4 acc[RBW][NB];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = blockIdx.x; t < P.ntiles; t += gridDim.x) {
+        int b = t;
+        const int txi = b % P.tiles_x; b /= P.tiles_x;
+        const int tyi = b % P.tiles_y;
+        const int img = b / P.tiles_y;
+        const int ty0 = tyi * P.TH, tx0 = txi * P.TW;
+        const int iy0 = P.S * ty0 - P.pad, ix0 = P.S * tx0 - P.pad;
+        __syncthreads();                                     // previous tile consumed
+        // ---- big halo tile
+        if constexpr (CAK == 4) {
+            const float* src = P.big + (int64_t)img * P.hb * P.wb * 3;
+            const int rowf = P.IW * 3;
+            for (int i = tid; i < P.IH * rowf; i += DC_THREADS) {
+                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                float v = 0.f;
+                if ((unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb) v = src[((int64_t)gy * P.wb + gx) * 3 + ch];
+                bigt[(iy * P.IW + ix) * 4 + ch] = v;
+            }
+        } else {
+            constexpr int C4 = CAK / 4;
+            const float* src = P.big + (int64_t)img * P.hb * P.wb * P.ldb;
+            for (int i = tid; i < P.IH * P.IW * C4; i += DC_THREADS) {
+                const int pi = i / C4, c = (i - pi * C4) * 4;
+                const int iy = pi / P.IW, ix = pi - iy * P.IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                float4 v = zero4();
+                if (c < P.CA && (unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb) v = ldg4(src + ((int64_t)gy * P.wb + gx) * P.ldb + c);
+                *reinterpret_cast<float4*>(&bigt[pi * CAP + c]) = v;
+            }
+        }
+        // ---- small tile (zero outside the grid: those pixels contribute nothing)
+        {
+            const int C4 = NP / 4;
+            const float* p1 = P.s1 + (int64_t)img * P.hs * P.ws * P.ld1;
+            const float* p2 = P.s2 ? P.s2 + (int64_t)(img % P.nmod2) * P.hs * P.ws * P.ld2 : nullptr;
+            for (int i = tid; i < npix * C4; i += DC_THREADS) {
+                const int pi = i / C4, c = (i - pi * C4) * 4;
+                const int ty = pi / P.TW, tx = pi - ty * P.TW;
+                const int gy = ty0 + ty, gx = tx0 + tx;
+                float4 v = zero4();
+                if (c < P.CB && gy < P.hs && gx < P.ws) {
+                    const int64_t pix = (int64_t)gy * P.ws + gx;
+                    v = c < P.c1 ? ldg4(p1 + pix * P.ld1 + c) : ldg4(p2 + pix * P.ld2 + (c - P.c1));
+                }
+                *reinterpret_cast<float4*>(&smallt[pi * CBP + c]) = v;
+            }
+        }
+        __syncthreads();
+        // ---- K loop over the tile's pixels, 16 per chunk: lane kg takes pixels 16c + 4kg + t
+        for (int c = 0; c < npix; c += 16) {
+            const int p0 = c + 4 * kg;
+            int pb[4], ps[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int p = p0 + tt, ty = p >> P.tw_sh, tx = p - (ty << P.tw_sh);
+                pb[tt] = ((P.S * ty) * P.IW + P.S * tx) * CAP;
+                ps[tt] = p * CBP;
+            }
+            float bv[NB][4];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) bv[nb][tt] = smallt[ps[tt] + nb * 16 + l15];
+#pragma unroll
+            for (int rb = 0; rb < RBW; ++rb) {
+                float av[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) av[tt] = bigt[pb[tt] + aoff[rb]];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], bv[nb][tt], acc[rb][nb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial -> slab[block][m][n]
+    float* sl = P.slab + (int64_t)blockIdx.x * P.M * NP;
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = (wv * RBW + rb) * 16 + 4 * kg + r;
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) sl[(int64_t)m * NP + nb * 16 + l15] = acc[rb][nb][r];
+        }
+}
+
+}  // namespace ctx

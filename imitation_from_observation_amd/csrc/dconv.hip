@@ -1,0 +1,203 @@
+// dconv.hip -- launchers of the narrow-channel direct convolutions (dconv.h): tap tables, tile choice, LDS budget, dispatch.
+#include <cstdio>
+#include <cstdlib>
+
+#include "dconv.h"
+#include "launch.h"
+
+namespace ctx {
+
+namespace {
+constexpr int LDS_BUDGET = 150 * 1024;      // of the 160 KiB per CU: one block of 8 waves
+
+int cik_of(int CI) { return CI == 3 ? 4 : CI <= 8 ? 8 : CI <= 16 ? 16 : CI <= 32 ? 32 : 64; }
+
+template <int CIK, int MI>
+void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds) {
+#define DC_CASE(nb)                                                                                                          \
+    case nb: {                                                                                                               \
+        static bool raised = false;                                                                                          \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET + 8192); raised = true; } \
+        hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, nb>), grid, dim3(DC_THREADS), lds, s, P);                              \
+        break;                                                                                                               \
+    }
+    switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
+#undef DC_CASE
+}
+
+template <int CIK>
+void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, dim3 grid, size_t lds) {
+    if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds);
+    else launch_fwd_nb<CIK, 1>(s, P, NB, grid, lds);
+}
+}  // namespace
+
+bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 32 || CI == 64) && N >= 1 && N <= 128; }
+
+// Fills tiles / LDS split and launches.  `span` = extent of the tap offsets (5 for the 5x5 taps over the input, 3 for a
+// stride-2 transposed conv over its small grid).
+static void dconv_launch(hipStream_t s, DcFwd P, int span) {
+    const int CIK = cik_of(P.CI), CIP = dc_cip(CIK);
+    int NB = (P.N + 15) / 16;
+    NB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
+    const int NP = NB * 16, TPC = CIK >= 16 ? 1 : 16 / CIK;
+    // tile: TW = the logical row (16 / 32 / 64 wide grids) capped at 32; TH = the divisor of hlog that fills the 8 * MI row
+    // blocks best within the LDS budget (a tile of fewer row blocks leaves waves idle but multiplies nothing extra)
+    P.TW = P.wlog >= 32 ? 32 : 16;
+    int best_th = 1, best_mi = 1;
+    double best = -1;
+    for (int mi = 1; mi <= 2; ++mi)
+        for (int th = 1; th <= 16; ++th) {
+            const int nrb = th * (P.TW / 16);
+            if (nrb > DC_NW * mi) break;
+            const int ih = P.S * (th - 1) + span, iw = P.S * (P.TW - 1) + span;
+            const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
+            if (tile + (size_t)TPC * CIK * NP * 4 + 256 > (size_t)LDS_BUDGET) break;
+            const int tiles = (P.hlog + th - 1) / th;
+            // useful MFMA work per block slot (row blocks really used over the 8*mi slots), discounted by ragged last tiles and the halo
+            const double eff = (double)P.hlog / (tiles * th) * nrb / (DC_NW * mi) * (mi == 2 ? 1.15 : 1.0) * ((double)th / ih);
+            if (eff > best) { best = eff; best_th = th; best_mi = mi; }
+        }
+    P.TH = best_th;
+    const int MI = best_mi;
+    P.IH = P.S * (P.TH - 1) + span;
+    P.IW = P.S * (P.TW - 1) + span;
+    P.tiles_y = (P.hlog + P.TH - 1) / P.TH;
+    P.tiles_x = (P.wlog + P.TW - 1) / P.TW;
+    const size_t tile = (size_t)((P.IH * P.IW * CIP + 3) & ~3) * 4;
+    int maxt = 0;
+    for (int c = 0; c < P.ncls; ++c) maxt = P.cls[c].ntaps > maxt ? P.cls[c].ntaps : maxt;
+    int gt = (int)(((size_t)LDS_BUDGET - tile - 256) / ((size_t)CIK * NP * 4));
+    gt = gt / TPC * TPC;
+    if (gt > (maxt + TPC - 1) / TPC * TPC) gt = (maxt + TPC - 1) / TPC * TPC;
+    if (gt < TPC) gt = TPC;
+    P.GT = gt;
+    const size_t lds = tile + (size_t)gt * CIK * NP * 4 + (size_t)(gt + 4) * 4;
+    const dim3 grid((unsigned)(P.nimg * P.tiles_y * P.tiles_x));
+    switch (CIK) {
+        case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds); break;
+        case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds); break;
+        case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds); break;
+        case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds); break;
+        default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds); break;
+    }
+}
+
+// conv2d 5x5, stride s, TF SAME (pad_before = pad): out [nimg, hin/s, win/s, N]; w[tap][k][n] (wmode 0) or [tap][n][k] (1)
+void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
+    P.S = stride; P.y_org = -pad; P.x_org = -pad;
+    P.hlog = P.hout = P.hin / stride; P.wlog = P.wout = P.win / stride; P.osc = 1;
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0};
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)ky, (int16_t)kx, (int16_t)(ky * 5 + kx), 0};
+    dconv_launch(s, P, 5);
+}
+
+// conv2d_transpose 5x5 stride 1 (SAME pad 2): out[q] = sum_taps in[q + 2 - tap] * w[tap]  -- a correlation with the mirrored offsets
+void dconv_convt1(hipStream_t s, DcFwd P) {
+    P.S = 1; P.y_org = -2; P.x_org = -2;
+    P.hlog = P.hout = P.hin; P.wlog = P.wout = P.win; P.osc = 1;
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0};
+    for (int ky = 0; ky < 5; ++ky)
+        for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)(4 - ky), (int16_t)(4 - kx), (int16_t)(ky * 5 + kx), 0};
+    dconv_launch(s, P, 5);
+}
+
+// conv2d_transpose 5x5 stride 2 (the input gradient of the SAME stride-2 conv, pad_before 1): output pixel (2i'+py, 2j'+px)
+// takes taps ky = par + 2 sy (par = (py + 1) & 1) from input row i' + off - sy (off = (py + 1 - par) / 2): KmConvTGather's classes
+void dconv_convt2(hipStream_t s, DcFwd P) {
+    P.S = 1; P.y_org = -1; P.x_org = -1;
+    P.hlog = P.hin; P.wlog = P.win; P.hout = 2 * P.hin; P.wout = 2 * P.win; P.osc = 2;
+    P.ncls = 4;
+    int nt = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int pary = (py + 1) & 1, parx = (px + 1) & 1, nty = (5 - pary + 1) / 2, ntx = (5 - parx + 1) / 2;
+        const int oy = (py + 1 - pary) / 2, ox = (px + 1 - parx) / 2;
+        P.cls[c] = DcClass{nt, nty * ntx, py, px};
+        for (int sy = 0; sy < nty; ++sy)
+            for (int sx = 0; sx < ntx; ++sx)
+                P.taps[nt++] = DcTap{(int16_t)(oy - sy + 1), (int16_t)(ox - sx + 1), (int16_t)((pary + 2 * sy) * 5 + parx + 2 * sx), 0};
+    }
+    dconv_launch(s, P, 3);
+}
+
+// ---- filter gradient ------------------------------------------------------------------------------------------
+// out[m][n] = sum over slabs in fixed order
+__global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int M, int NP, int CB, float* __restrict__ out) {
+    const int64_t total = (int64_t)M * CB;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / CB), n = (int)(i - (int64_t)m * CB);
+        const float* p = slab + (int64_t)m * NP + n;
+        float v = 0.f;
+        for (int s = 0; s < nslab; ++s) v += p[(int64_t)s * M * NP];
+        out[i] = v;
+    }
+}
+
+namespace {
+template <int CAK, int RBW>
+void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds) {
+#define DC_CASE(nb)                                                                                                          \
+    case nb: {                                                                                                               \
+        static bool raised = false;                                                                                          \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET + 8192); raised = true; } \
+        hipLaunchKernelGGL((dconv_wgrad_kernel<CAK, RBW, nb>), grid, dim3(DC_THREADS), lds, s, P);                           \
+        break;                                                                                                               \
+    }
+    switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
+#undef DC_CASE
+}
+}  // namespace
+
+// dw[tap][a][b] (a: channels of `big`, b: channels of [s1 | s2]); slab: scratch of slab_floats floats
+void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
+    const int CAK = P.CA == 3 ? 4 : P.CA <= 8 ? 8 : P.CA <= 16 ? 16 : 32;
+    const int CAP = CAK == 4 ? 4 : CAK + 4;
+    int NB = (P.CB + 15) / 16;
+    NB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
+    const int NP = NB * 16, CBP = NP + 4;
+    P.M = 25 * P.CA;
+    const int nrb = (P.M + 15) / 16;
+    const int RBW = (nrb + DC_NW - 1) / DC_NW;            // 1 (CA 3), 2 (8), 4 (16), 7 (32)
+    P.RBW = RBW;
+    P.TW = P.ws >= 64 ? 64 : P.ws >= 32 ? 32 : 16;
+    P.tw_sh = P.TW == 64 ? 6 : P.TW == 32 ? 5 : 4;
+    // TH: the divisor-like height that keeps big halo + small tile inside the budget with the least halo overhead
+    int best_th = 1;
+    double best = -1;
+    for (int th = 1; th <= 32; ++th) {
+        const int ih = P.S * (th - 1) + 5, iw = P.S * (P.TW - 1) + 5;
+        const size_t lds = (size_t)((ih * iw * CAP + 3) & ~3) * 4 + (size_t)th * P.TW * CBP * 4;
+        if (lds > (size_t)LDS_BUDGET) break;
+        const int tiles = (P.hs + th - 1) / th;
+        const double eff = (double)P.hs / (tiles * th) * ((double)th / (th + 4.0 / P.S));
+        if (eff > best) { best = eff; best_th = th; }
+    }
+    P.TH = best_th;
+    P.IH = P.S * (P.TH - 1) + 5;
+    P.IW = P.S * (P.TW - 1) + 5;
+    P.tiles_y = (P.hs + P.TH - 1) / P.TH;
+    P.tiles_x = (P.ws + P.TW - 1) / P.TW;
+    P.ntiles = P.nimg * P.tiles_y * P.tiles_x;
+    const size_t lds = (size_t)((P.IH * P.IW * CAP + 3) & ~3) * 4 + (size_t)P.TH * P.TW * CBP * 4;
+    int64_t nblk = 256;                                    // one persistent block per CU
+    const int64_t cap = slab_floats / ((int64_t)P.M * NP);
+    if (nblk > cap) nblk = cap;
+    if (nblk > P.ntiles) nblk = P.ntiles;
+    if (nblk < 1) nblk = 1;
+    P.slab = slab;
+    const dim3 grid((unsigned)nblk);
+#define DC_WG(cak, rbw) launch_wg_nb<cak, rbw>(s, P, NB, grid, lds)
+    if (CAK == 4) DC_WG(4, 1);
+    else if (CAK == 8) DC_WG(8, 2);
+    else if (CAK == 16) DC_WG(16, 4);
+    else DC_WG(32, 7);
+#undef DC_WG
+    const int64_t total = (int64_t)P.M * P.CB;
+    int64_t rb = (total + 255) / 256;
+    if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)slab, (int)nblk, P.M, NP, P.CB, P.out);
+}
+
+}  // namespace ctx

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "igemm.h"
+#include "dconv.h"
 
 namespace ctx {
 
@@ -41,6 +42,14 @@ void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& 
 void conv3_fwd(hipStream_t s, const KmC3Gather& a, const NmC3Weights& b, Epi ep, int M, int N, SplitWs ws);
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws);
 void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, Epi ep, int N, SplitWs ws);
+
+// narrow-channel direct convolutions (dconv.h / dconv.hip).  P carries tensors, channel counts, filter and epilogue; the
+// launchers fill the tap tables, tiles and LDS split.  dconv_ok: the channel counts the kernels are instantiated for.
+bool dconv_ok(int CI, int N);
+void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad);        // conv2d 5x5 SAME (also: input gradient of conv2d_transpose)
+void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 1 (also: input gradient of a stride-1 conv2d)
+void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
+void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   // filter gradient of either, 25 taps in one launch
 
 // conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
 // product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a
