@@ -93,6 +93,7 @@ struct ctx_handle {
     hipStream_t aux[NLANE] = {};
     hipEvent_t ev_fork[NLANE] = {}, ev_join[NLANE] = {};
     float *slabL[NLANE] = {}, *scratchL[NLANE] = {};
+    float *wpack = nullptr, *wpackL[NLANE] = {};   // dconv's re-packed filters, one buffer per stream lane (concurrent launches)
     bool overlap = true;
     // hipGraph cache of the two inference forwards (reward hook: batch-25 calls are launch-bound): key = mode * 2^20 + B
     struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; };
@@ -327,9 +328,11 @@ int alloc_buffers(ctx_handle* h) {
     TRY(dev_alloc(h, &h->scratch, std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
     h->slab_floats = 32ll << 20;
     TRY(dev_alloc(h, &h->slab, h->slab_floats));
+    TRY(dev_alloc(h, &h->wpack, DC_WPACK_FLOATS));
     for (int l = 0; l < ctx_handle::NLANE; ++l) {
         TRY(dev_alloc(h, &h->slabL[l], h->slab_floats));
         TRY(dev_alloc(h, &h->scratchL[l], std::max<int64_t>(4 * LOSS_BLOCKS, (int64_t)COLSUM_SPLITS * maxc)));
+        TRY(dev_alloc(h, &h->wpackL[l], DC_WPACK_FLOATS));
     }
     TRY(dev_alloc(h, &h->scalars, 4));
     TRY(dev_alloc(h, &h->zeros, 64));
@@ -353,11 +356,11 @@ SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.pr
 struct LaneSwap {
     ctx_handle* h;
     hipStream_t s0;
-    float *sl0, *sc0;
-    LaneSwap(ctx_handle* h_, int lane) : h(h_), s0(h_->stream), sl0(h_->slab), sc0(h_->scratch) {
-        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane];
+    float *sl0, *sc0, *wp0;
+    LaneSwap(ctx_handle* h_, int lane) : h(h_), s0(h_->stream), sl0(h_->slab), sc0(h_->scratch), wp0(h_->wpack) {
+        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane]; h->wpack = h->wpackL[lane];
     }
-    ~LaneSwap() { h->stream = s0; h->slab = sl0; h->scratch = sc0; }
+    ~LaneSwap() { h->stream = s0; h->slab = sl0; h->scratch = sc0; h->wpack = wp0; }
 };
 bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux[0] && !h->prof_on && !h->capturing; }
 // fork: `lane` starts after everything enqueued so far on the CURRENT stream; join: the current stream
@@ -376,14 +379,14 @@ struct Side {
     ctx_handle* h;
     bool on;
     hipStream_t s0 = nullptr;
-    float *sl0 = nullptr, *sc0 = nullptr;
+    float *sl0 = nullptr, *sc0 = nullptr, *wp0 = nullptr;
     Side(ctx_handle* h_, int lane) : h(h_), on(lane >= 0 && use_lanes(h_)) {
         if (!on) return;
         fork(h, lane);
-        s0 = h->stream; sl0 = h->slab; sc0 = h->scratch;
-        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane];
+        s0 = h->stream; sl0 = h->slab; sc0 = h->scratch; wp0 = h->wpack;
+        h->stream = h->aux[lane]; h->slab = h->slabL[lane]; h->scratch = h->scratchL[lane]; h->wpack = h->wpackL[lane];
     }
-    ~Side() { if (on) { h->stream = s0; h->slab = sl0; h->scratch = sc0; } }
+    ~Side() { if (on) { h->stream = s0; h->slab = sl0; h->scratch = sc0; h->wpack = wp0; } }
 };
 constexpr int LANE_CTX = 0, LANE_DW = 1;
 
@@ -420,6 +423,10 @@ KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nul
 
 // position-major launches (KmConvGatherQ / KmConvTGatherQ) pay once a block is mostly full: rows = images
 // (transposed conv on 4x4 grids: 64 problems of 1..9 taps leave a long tail; the class-major launch stays faster there)
+// the 3-channel edge layers (h0_conv forward / filter gradient, d_h4 input / filter gradient) on the direct kernels of dconv.h:
+// the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack passes go away
+bool use_dc3() { static const bool on = [] { const char* e = getenv("CTX_DCONV"); return !(e && e[0] == '0'); }(); return on; }
+
 bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
 
 int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = getenv("CTX_Q_MINPOS"); return e ? atoi(e) : -1; }(); return v >= 0 ? v : (h->cfg.precision ? 0 : 64); }
@@ -431,7 +438,11 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
-    if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
+    if (ca == 3 && use_dc3()) {
+        DcFwd P{};
+        P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
+        dconv_conv(h->stream, P, 2, 1);
+    } else if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
     else if (use_q(nimg)) conv_fwd_q(h->stream, KmConvGatherQ{x, ca, make_posgeo(hs, ws, hb, wb, 2, 1, 5, ca / KC), nimg, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ep, cb, ws_of(h));
     else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
@@ -524,7 +535,8 @@ void forward(ctx_handle* h, int B, Mode mode) {
     float* src_z = h->Z + 2ll * B * F;
     const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
     // refresh the 4-channel copy of the frames in use (what the cin = 3 loaders read)
-    if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
+    if (use_dc3()) {}
+    else if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
     else pack_c4(h, h->img + B * npi, (mode == MODE_ENCODE ? 1ll : 2ll) * B * h->H * h->W);
     if (lanes) {
         fork(h, LANE_CTX);
@@ -585,7 +597,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     {
         ProfScope ps(h, "losses", K_EW, 0.0);
         losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
-        pack_c4(h, h->dout, 2ll * B * h->H * h->W);
+        if (!use_dc3()) pack_c4(h, h->dout, 2ll * B * h->H * h->W);
     }
 
     // ---- decoder, both passes at once (batch 2B)
@@ -608,7 +620,19 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         Epi ed;
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
-        if (ca == 3) {
+        if (ca == 3 && use_dc3()) {
+            { Side sd(h, LANE_DW);
+              bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
+              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl);
+              DcWgrad Wg{};
+              Wg.big = dy; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dec_in; Wg.ld1 = c1; Wg.c1 = c1; Wg.s2 = h->c[4 - k]; Wg.ld2 = c2; Wg.nmod2 = B; Wg.CB = cb;
+              Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = 2 * B; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
+              dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl);
+              DcFwd D{};
+              D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack;
+              dconv_conv(h->stream, D, 2, 1); }
+        } else if (ca == 3) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
               ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{c4of(h, dy), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
@@ -681,7 +705,12 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 Side sd(h, dw_lane);
                 bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
-                conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
+                if (use_dc3()) {
+                    DcWgrad Wg{};
+                    Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
+                    Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = nimg; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
+                    dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats);
+                } else conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 break;   // no gradient w.r.t. the frame
             }
             { Side sd(h, dw_lane);

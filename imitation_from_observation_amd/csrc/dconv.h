@@ -34,7 +34,8 @@ constexpr int DC_THREADS = 512;          // 8 waves: one or two 16-row blocks ea
 constexpr int DC_NW = DC_THREADS / 64;
 
 struct DcTap { int16_t dy, dx, wt, pad; };        // input-tile pixel offset of the tap; filter tap index ky * 5 + kx
-struct DcClass { int tap0, ntaps, oy, ox; };       // taps [tap0, tap0 + ntaps); physical output pixel = (osc*y + oy, osc*x + ox)
+struct DcClass { int tap0, ntaps, oy, ox, pslot0; };   // taps [tap0, tap0 + ntaps); physical output pixel = (osc*y + oy, osc*x + ox);
+                                                        // pslot0: first slot of the class in the packed filter (classes padded to whole chunks)
 
 struct DcFwd {
     const float* x1; int ld1; int c1;              // input channels [0, c1)
@@ -47,6 +48,9 @@ struct DcFwd {
     int TH, TW;                                    // tile of logical outputs, TH * TW = 16 * DC_NW * MI
     int IH, IW;                                    // input tile incl. halo
     const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
+    float* wp;                                     // the filter re-packed for the LDS image: wp[slot][k / 4][n (NP)][k & 3], slots in tap-list
+                                                   // order (dconv_pack_kernel, one tiny launch before the convolution): a block's staging
+                                                   // is then a straight float4 copy instead of 25 * CIK * NP strided scalar gathers
     int N;                                         // real output channels (<= 16 * NB)
     int GT;                                        // taps staged in LDS per pass
     int ncls; DcClass cls[4]; DcTap taps[DC_MAXTAPS];
@@ -56,6 +60,26 @@ struct DcFwd {
 };
 
 __host__ __device__ inline int dc_cip(int cik) { return cik + 4 - (cik == 4 ? 4 : 0); }      // LDS pixel stride: CIK + 4 (bank spread), 4 for the 3-channel tile
+
+// wp[slot][k / 4][n][k & 3] for every class-padded tap slot (zeros in the padding: slots past a class's taps, k >= CI, n >= N)
+template <int CIK>
+__global__ __launch_bounds__(256) void dconv_pack_kernel(const DcFwd P, int NP, int nslots) {
+    constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;
+    const int total = nslots * CIK * NP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int n = i % NP, ek = i / NP, slot = ek / CIK, k = ek - slot * CIK;
+        float v = 0.f;
+        int ci = 0;
+        while (ci + 1 < P.ncls && slot >= P.cls[ci + 1].pslot0) ++ci;
+        const int e = slot - P.cls[ci].pslot0;
+        if (e < P.cls[ci].ntaps && n < P.N && k < P.CI) {
+            const int wt = P.taps[P.cls[ci].tap0 + e].wt;
+            v = P.wmode ? P.w[((int64_t)wt * P.N + n) * P.CI + k] : P.w[((int64_t)wt * P.CI + k) * P.N + n];
+        }
+        P.wp[((int64_t)(ek >> 2) * NP + n) * 4 + (ek & 3)] = v;
+    }
+    (void)TPC;
+}
 
 // LDS: tile[IH*IW][CIP] | W4[GTK/4][NP][4] | toff[GTP]     (GTK = staged taps (padded to whole 16-k chunks) * CIK)
 template <int CIK, int MI, int NB>
@@ -131,15 +155,11 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
             const int nt = cl.ntaps - t0 < P.GT ? cl.ntaps - t0 : P.GT;
             const int ntp = (nt + TPC - 1) / TPC * TPC;
             __syncthreads();                                 // tile complete / previous stage consumed
-            // ---- stage the filter taps [t0, t0 + nt) of this class: W4[(e*CIK + k) / 4][n][k & 3]
-            for (int i = tid; i < ntp * CIK * NP; i += DC_THREADS) {
-                const int n = i % NP, ek = i / NP, e = ek / CIK, k = ek - e * CIK;
-                float v = 0.f;
-                if (e < nt && n < P.N && k < P.CI) {
-                    const int wt = P.taps[cl.tap0 + t0 + e].wt;
-                    v = P.wmode ? P.w[((int64_t)wt * P.N + n) * P.CI + k] : P.w[((int64_t)wt * P.CI + k) * P.N + n];
-                }
-                W4[((ek >> 2) * NP + n) * 4 + (ek & 3)] = v;
+            // ---- stage the filter taps [t0, t0 + nt) of this class: W4[(e*CIK + k) / 4][n][k & 3], already in that order in wp
+            {
+                const float4* src = reinterpret_cast<const float4*>(P.wp) + (int64_t)(cl.pslot0 + t0) * (CIK / 4) * NP;
+                float4* dst = reinterpret_cast<float4*>(W4);
+                for (int i = tid; i < ntp * (CIK / 4) * NP; i += DC_THREADS) dst[i] = src[i];
             }
             for (int e = tid; e < ntp; e += DC_THREADS) {
                 const DcTap tp = P.taps[cl.tap0 + t0 + (e < nt ? e : 0)];

@@ -74,6 +74,20 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     P.GT = gt;
     const size_t lds = tile + (size_t)gt * CIK * NP * 4 + (size_t)(gt + 4) * 4;
     const dim3 grid((unsigned)(P.nimg * P.tiles_y * P.tiles_x));
+    // the filter in the LDS image's order (classes padded to whole 16-k chunks)
+    int nslots = 0;
+    for (int c = 0; c < P.ncls; ++c) { P.cls[c].pslot0 = nslots; nslots += (P.cls[c].ntaps + TPC - 1) / TPC * TPC; }
+    {
+        const int total = nslots * CIK * NP;
+        const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
+        switch (CIK) {
+            case 4: hipLaunchKernelGGL((dconv_pack_kernel<4>), pg, dim3(256), 0, s, P, NP, nslots); break;
+            case 8: hipLaunchKernelGGL((dconv_pack_kernel<8>), pg, dim3(256), 0, s, P, NP, nslots); break;
+            case 16: hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, NP, nslots); break;
+            case 32: hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, NP, nslots); break;
+            default: hipLaunchKernelGGL((dconv_pack_kernel<64>), pg, dim3(256), 0, s, P, NP, nslots); break;
+        }
+    }
     switch (CIK) {
         case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds); break;
         case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds); break;
@@ -87,7 +101,7 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
 void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
     P.S = stride; P.y_org = -pad; P.x_org = -pad;
     P.hlog = P.hout = P.hin / stride; P.wlog = P.wout = P.win / stride; P.osc = 1;
-    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0};
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0};
     for (int ky = 0; ky < 5; ++ky)
         for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)ky, (int16_t)kx, (int16_t)(ky * 5 + kx), 0};
     dconv_launch(s, P, 5);
@@ -97,7 +111,7 @@ void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
 void dconv_convt1(hipStream_t s, DcFwd P) {
     P.S = 1; P.y_org = -2; P.x_org = -2;
     P.hlog = P.hout = P.hin; P.wlog = P.wout = P.win; P.osc = 1;
-    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0};
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0};
     for (int ky = 0; ky < 5; ++ky)
         for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)(4 - ky), (int16_t)(4 - kx), (int16_t)(ky * 5 + kx), 0};
     dconv_launch(s, P, 5);
@@ -114,7 +128,7 @@ void dconv_convt2(hipStream_t s, DcFwd P) {
         const int py = c >> 1, px = c & 1;
         const int pary = (py + 1) & 1, parx = (px + 1) & 1, nty = (5 - pary + 1) / 2, ntx = (5 - parx + 1) / 2;
         const int oy = (py + 1 - pary) / 2, ox = (px + 1 - parx) / 2;
-        P.cls[c] = DcClass{nt, nty * ntx, py, px};
+        P.cls[c] = DcClass{nt, nty * ntx, py, px, 0};
         for (int sy = 0; sy < nty; ++sy)
             for (int sx = 0; sx < ntx; ++sx)
                 P.taps[nt++] = DcTap{(int16_t)(oy - sy + 1), (int16_t)(ox - sx + 1), (int16_t)((pary + 2 * sy) * 5 + parx + 2 * sx), 0};
@@ -181,7 +195,10 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
     P.tiles_x = (P.ws + P.TW - 1) / P.TW;
     P.ntiles = P.nimg * P.tiles_y * P.tiles_x;
     const size_t lds = (size_t)((P.IH * P.IW * CAP + 3) & ~3) * 4 + (size_t)P.TH * P.TW * CBP * 4;
-    int64_t nblk = 256;                                    // one persistent block per CU
+    // persistent blocks, as many per CU as LDS admits (up to 3): one block's tile loads run under another's MFMA loop
+    int occ = (int)((size_t)LDS_BUDGET / lds);
+    occ = occ < 1 ? 1 : occ > 3 ? 3 : occ;
+    int64_t nblk = 256 * occ;
     const int64_t cap = slab_floats / ((int64_t)P.M * NP);
     if (nblk > cap) nblk = cap;
     if (nblk > P.ntiles) nblk = P.ntiles;

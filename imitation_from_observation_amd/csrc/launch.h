@@ -46,6 +46,7 @@ void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, 
 // narrow-channel direct convolutions (dconv.h / dconv.hip).  P carries tensors, channel counts, filter and epilogue; the
 // launchers fill the tap tables, tiles and LDS split.  dconv_ok: the channel counts the kernels are instantiated for.
 bool dconv_ok(int CI, int N);
+constexpr int64_t DC_WPACK_FLOATS = 40ll * 64 * 128;        // P.wp: <= 37 class-padded tap slots x 64 k x 128 n
 void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad);        // conv2d 5x5 SAME (also: input gradient of conv2d_transpose)
 void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 1 (also: input gradient of a stride-1 conv2d)
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
