@@ -425,7 +425,8 @@ KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nul
 // (transposed conv on 4x4 grids: 64 problems of 1..9 taps leave a long tail; the class-major launch stays faster there)
 // the 3-channel edge layers (h0_conv forward / filter gradient, d_h4 input / filter gradient) on the direct kernels of dconv.h:
 // the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack passes go away
-bool use_dc3() { static const bool on = [] { const char* e = getenv("CTX_DCONV"); return !(e && e[0] == '0'); }(); return on; }
+// (measured at B = 256, 64x64: NOT faster than the 4-channel-copy implicit GEMM -- 14.9 vs 14.5 ms per step -- so off by default: CTX_DCONV_C3=1)
+bool use_dc3() { static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return e && e[0] == '1'; }(); return on; }
 
 bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
 

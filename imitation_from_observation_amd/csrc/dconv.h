@@ -45,7 +45,7 @@ struct DcFwd {
     int S;                                         // input pixels per logical output pixel (1 | 2)
     int y_org, x_org;                              // input pixel of logical output (0,0) at tap offset (0,0)
     int hlog, wlog;                                // logical output grid = the GEMM's row space (transposed stride 2: the small grid)
-    int TH, TW;                                    // tile of logical outputs, TH * TW = 16 * DC_NW * MI
+    int TH, TW;                                    // tile of logical outputs: TH * TW / 16 row blocks <= DC_NW * MI
     int IH, IW;                                    // input tile incl. halo
     const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
     float* wp;                                     // the filter re-packed for the LDS image: wp[slot][k / 4][n (NP)][k & 3], slots in tap-list
@@ -168,26 +168,39 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
             __syncthreads();
 
             const int nchunks = active ? ntp / TPC * CPT : 0;
-            for (int c = 0; c < nchunks; ++c) {
+            // software pipeline: the LDS reads of chunk c + 1 (tap offset -> A / B fragments, a dependent chain of two LDS
+            // latencies) are issued before the 4 * MI * NB MFMAs of chunk c
+            float4 a4[2][MI], b4[2][NB];
+            auto fetch = [&](int c, int buf) {
                 const int k16 = 16 * c + 4 * kg;              // this lane's first k of the chunk, in staged-K coordinates
                 const int e = k16 / CIK, kin = k16 - e * CIK;
                 const int to = toff[e] + kin;
-                float4 a4[MI], b4[NB];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a4[mi] = *reinterpret_cast<const float4*>(&tile[abase[mi] + to]);
+                for (int mi = 0; mi < MI; ++mi) a4[buf][mi] = *reinterpret_cast<const float4*>(&tile[abase[mi] + to]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) b4[nb] = *reinterpret_cast<const float4*>(&W4[((4 * c + kg) * NP + nb * 16 + l15) * 4]);
+                for (int nb = 0; nb < NB; ++nb) b4[buf][nb] = *reinterpret_cast<const float4*>(&W4[((4 * c + kg) * NP + nb * 16 + l15) * 4]);
+            };
+            auto mma = [&](int buf) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const float av = t == 0 ? a4[mi].x : t == 1 ? a4[mi].y : t == 2 ? a4[mi].z : a4[mi].w;
+                        const float av = t == 0 ? a4[buf][mi].x : t == 1 ? a4[buf][mi].y : t == 2 ? a4[buf][mi].z : a4[buf][mi].w;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            const float bv = t == 0 ? b4[nb].x : t == 1 ? b4[nb].y : t == 2 ? b4[nb].z : b4[nb].w;
+                            const float bv = t == 0 ? b4[buf][nb].x : t == 1 ? b4[buf][nb].y : t == 2 ? b4[buf][nb].z : b4[buf][nb].w;
                             acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
                         }
                     }
+                }
+            };
+            if (nchunks > 0) fetch(0, 0);
+            for (int c = 0; c < nchunks; c += 2) {
+                if (c + 1 < nchunks) fetch(c + 1, 1);
+                mma(0);
+                if (c + 1 < nchunks) {
+                    if (c + 2 < nchunks) fetch(c + 2, 0);
+                    mma(1);
                 }
             }
         }

@@ -27,7 +27,9 @@ void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds)
 
 template <int CIK>
 void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, dim3 grid, size_t lds) {
-    if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds);
+    if (MI == 4) launch_fwd_nb<CIK, 4>(s, P, NB, grid, lds);
+    else if (MI == 3) launch_fwd_nb<CIK, 3>(s, P, NB, grid, lds);
+    else if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds);
     else launch_fwd_nb<CIK, 1>(s, P, NB, grid, lds);
 }
 }  // namespace
@@ -43,21 +45,32 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     const int NP = NB * 16, TPC = CIK >= 16 ? 1 : 16 / CIK;
     // tile: TW = the logical row (16 / 32 / 64 wide grids) capped at 32; TH = the divisor of hlog that fills the 8 * MI row
     // blocks best within the LDS budget (a tile of fewer row blocks leaves waves idle but multiplies nothing extra)
-    P.TW = P.wlog >= 32 ? 32 : 16;
-    int best_th = 1, best_mi = 1;
+    // tile: TW in {16, 32, 64} (<= the logical row), TH rows; MI = row blocks per wave.  Cost model: the matrix pipes are
+    // per SIMD and wave w sits on SIMD w % 4, so a tile takes the time of its busiest SIMD; scored as useful row blocks per
+    // (4 x busiest SIMD), times the share of real rows in ragged last tiles, times the halo overhead of the input tile.
+    int best_th = 1, best_mi = 1, best_tw = 16;
     double best = -1;
-    for (int mi = 1; mi <= 2; ++mi)
-        for (int th = 1; th <= 16; ++th) {
-            const int nrb = th * (P.TW / 16);
-            if (nrb > DC_NW * mi) break;
-            const int ih = P.S * (th - 1) + span, iw = P.S * (P.TW - 1) + span;
-            const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
-            if (tile + (size_t)TPC * CIK * NP * 4 + 256 > (size_t)LDS_BUDGET) break;
-            const int tiles = (P.hlog + th - 1) / th;
-            // useful MFMA work per block slot (row blocks really used over the 8*mi slots), discounted by ragged last tiles and the halo
-            const double eff = (double)P.hlog / (tiles * th) * nrb / (DC_NW * mi) * (mi == 2 ? 1.15 : 1.0) * ((double)th / ih);
-            if (eff > best) { best = eff; best_th = th; best_mi = mi; }
-        }
+    const int mi_max = NB >= 8 ? 2 : 4;                       // accumulators: MI * NB * 4 registers
+    for (int tw = 16; tw <= 64 && tw <= (P.wlog + 15) / 16 * 16; tw *= 2)
+        for (int mi = 1; mi <= mi_max; ++mi)
+            for (int th = 1; th <= 16; ++th) {
+                const int nrb = th * (tw / 16);
+                if (nrb > DC_NW * mi) break;
+                const int ih = P.S * (th - 1) + span, iw = P.S * (tw - 1) + span;
+                const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
+                const size_t need = tile + (size_t)TPC * CIK * NP * 4 + 256;
+                if (need > (size_t)LDS_BUDGET) break;
+                const bool two = 2 * (need + (size_t)3 * TPC * CIK * NP * 4) <= (size_t)LDS_BUDGET;   // two blocks per CU (with a few taps staged): one's staging under the other's MFMAs
+                int load[4] = {0, 0, 0, 0};
+                for (int w = 0; w * mi < nrb; ++w) load[w & 3] += nrb - w * mi < mi ? nrb - w * mi : mi;
+                int busiest = 1;
+                for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
+                const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
+                const double eff = (double)nrb / (4.0 * busiest) * ((double)P.hlog * P.wlog / ((double)tiles_y * th * tiles_x * tw)) *
+                                   ((double)(th * tw * P.S * P.S) / (ih * iw)) * (mi >= 2 ? 1.0 : 0.85) * (two ? 1.0 : 0.75);   // MI = 1 re-reads B per row block
+                if (eff > best) { best = eff; best_th = th; best_mi = mi; best_tw = tw; }
+            }
+    P.TW = best_tw;
     P.TH = best_th;
     const int MI = best_mi;
     P.IH = P.S * (P.TH - 1) + span;
@@ -67,7 +80,9 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     const size_t tile = (size_t)((P.IH * P.IW * CIP + 3) & ~3) * 4;
     int maxt = 0;
     for (int c = 0; c < P.ncls; ++c) maxt = P.cls[c].ntaps > maxt ? P.cls[c].ntaps : maxt;
-    int gt = (int)(((size_t)LDS_BUDGET - tile - 256) / ((size_t)CIK * NP * 4));
+    size_t wbudget = (size_t)LDS_BUDGET - tile - 256;
+    if (2 * (tile + 256 + (size_t)4 * TPC * CIK * NP * 4) <= (size_t)LDS_BUDGET) wbudget = (size_t)LDS_BUDGET / 2 - tile - 256;   // leave room for a second block
+    int gt = (int)(wbudget / ((size_t)CIK * NP * 4));
     gt = gt / TPC * TPC;
     if (gt > (maxt + TPC - 1) / TPC * TPC) gt = (maxt + TPC - 1) / TPC * TPC;
     if (gt < TPC) gt = TPC;

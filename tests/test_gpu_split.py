@@ -65,7 +65,7 @@ def test_split_mode_is_active_and_deterministic(T):
     np.testing.assert_array_equal(outs[0][0], outs[1][0])    # bit-reproducible (no atomics, fixed split-K order)
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
     assert not np.array_equal(outs[0][0], outs[2][0])        # and it is not the f32 path
-    assert relmax(outs[0][0], outs[2][0]) < TOL
+    assert relmax(outs[0][0], outs[2][0]) < 2 * TOL          # after an Adam step of lr 1e-3 on both: the product error, amplified once
 
 
 def test_split_adam_trajectory(T):
