@@ -71,6 +71,8 @@ SIGNATURES = {
     "ctx_encode": (_c.c_int, [_P, _U8, _c.c_int, _F, _F]),
     "ctx_translate_f32": (_c.c_int, [_P, _F, _F, _c.c_int, _c.c_int, _F, _F]),
     "ctx_encode_f32": (_c.c_int, [_P, _F, _c.c_int, _F]),
+    "ctx_reward_set_cache": (_c.c_int, [_P, _c.c_int, _F, _F, _c.c_int]),
+    "ctx_reward_costs": (_c.c_int, [_P, _c.c_int, _U8, _c.c_int, _c.c_float, _c.c_int, _F]),
     "ctx_train_step": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _c.c_float, _F]),
     "ctx_train_step_u8": (_c.c_int, [_P, _U8, _U8, _U8, _c.c_int, _c.c_float, _F]),
     "ctx_demos_upload": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),

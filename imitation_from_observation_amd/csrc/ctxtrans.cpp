@@ -108,6 +108,10 @@ struct ctx_handle {
     int vT = 0, vN = 0;
     float* lut = nullptr;
     int* choice = nullptr;    // [2 * max_batch]: choicesrc | choicetgt
+    // reward hook on the device (ctx_reward_*): per viewpoint the cached demo means [bs, F] and mean translated frames [bs, H, W, 3]
+    struct RewardCache { float* means = nullptr; float* imgs = nullptr; int bs = 0; };
+    std::vector<RewardCache> rcache;
+    float* rcosts = nullptr;
     float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
     int64_t slab_floats = 0;
     // data parallel over RCCL (ctx_dp_*): communicator, a stream for the collectives (they overlap the encoders' backward),
@@ -1014,6 +1018,7 @@ void ctx_destroy(ctx_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
+    for (auto& rc : h->rcache) { if (rc.means) (void)hipFree(rc.means); if (rc.imgs) (void)hipFree(rc.imgs); }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
     for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -1193,6 +1198,41 @@ int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* 
     if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
                                          hipMemcpyDeviceToHost, h->stream));
     if (frames_f32) HIP_TRY(h, hipMemcpyAsync(frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
+int ctx_reward_set_cache(ctx_handle* h, int vp, const float* means, const float* imgs, int bs) {
+    if (!h) return CTX_E_INVALID;
+    if (vp < 0 || vp >= 64 || !means || !imgs || bs <= 0 || bs > h->Bm) return fail(h, CTX_E_INVALID, "bad viewpoint / batch_size");
+    if (h->cfg.variant == CTX_VARIANT_INCEPTION2) return fail(h, CTX_E_INVALID, "the device reward path takes frames, not feature maps");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if ((int)h->rcache.size() <= vp) h->rcache.resize(vp + 1);
+    ctx_handle::RewardCache& rc = h->rcache[vp];
+    if (rc.means) { (void)hipFree(rc.means); (void)hipFree(rc.imgs); rc.means = rc.imgs = nullptr; }
+    const size_t nm = (size_t)bs * h->F * sizeof(float), ni = (size_t)bs * h->npi * sizeof(float);
+    if (hipMalloc((void**)&rc.means, nm) != hipSuccess || hipMalloc((void**)&rc.imgs, ni) != hipSuccess) return fail(h, CTX_E_NOMEM, "reward cache");
+    rc.bs = bs;
+    HIP_TRY(h, hipMemcpyAsync(rc.means, means, nm, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(rc.imgs, imgs, ni, hipMemcpyHostToDevice, h->stream));
+    if (!h->rcosts) TRY(dev_alloc(h, &h->rcosts, h->Bm));
+    return finish(h);
+}
+
+int ctx_reward_costs(ctx_handle* h, int vp, const uint8_t* frames, int npaths, float scale, int ablation, float* costs) {
+    if (!h) return CTX_E_INVALID;
+    if (vp < 0 || vp >= (int)h->rcache.size() || !h->rcache[vp].means) return fail(h, CTX_E_STATE, "ctx_reward_set_cache(vp = %d) first", vp);
+    const ctx_handle::RewardCache& rc = h->rcache[vp];
+    if (!frames || !costs || npaths <= 0 || ablation < 0 || ablation > 2) return fail(h, CTX_E_INVALID, "bad argument");
+    const int B = npaths * rc.bs;
+    TRY(check_B(h, B));
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t npi = h->npi;
+    HIP_TRY(h, hipMemcpyAsync(h->u8, frames, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
+    u8_to_f32(h->stream, h->u8, h->img + B * npi, B * npi);               // image_trans[0], base.py:116-119
+    if (ablation != 1) TRY(forward_inference(h, B, MODE_ENCODE));         // input_z: the `conv` encoder on the frames (base.py:234-235)
+    reward_costs(h->stream, h->Z + 2ll * B * h->Fp, h->Fp, h->F, h->img + B * npi, npi, rc.means, rc.imgs, rc.bs, B, scale, ablation, h->rcosts);
+    HIP_TRY(h, hipMemcpyAsync(costs, h->rcosts, (size_t)B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->last_B = 0;
     return finish(h);
 }

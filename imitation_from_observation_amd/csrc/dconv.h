@@ -34,8 +34,12 @@ constexpr int DC_THREADS = 512;          // 8 waves: one or two 16-row blocks ea
 constexpr int DC_NW = DC_THREADS / 64;
 
 struct DcTap { int16_t dy, dx, wt, pad; };        // input-tile pixel offset of the tap; filter tap index ky * 5 + kx
-struct DcClass { int tap0, ntaps, oy, ox, pslot0; };   // taps [tap0, tap0 + ntaps); physical output pixel = (osc*y + oy, osc*x + ox);
-                                                        // pslot0: first slot of the class in the packed filter (classes padded to whole chunks)
+struct DcClass {
+    int tap0, ntaps, oy, ox, pslot0;   // taps [tap0, tap0 + ntaps); physical output pixel = (osc*y + oy, osc*x + ox);
+                                       // pslot0: first slot of the class in the packed filter (classes padded to whole chunks)
+    int ntx, mdiv, dy0, dx0, sgn;      // tap e of the class sits at input-tile offset (dy0 + sgn * (e / ntx), dx0 + sgn * (e % ntx));
+                                       // e / ntx = (e * mdiv) >> 8 for e < 25 -- pure ALU, no table read in the MFMA loop
+};
 
 struct DcFwd {
     const float* x1; int ld1; int c1;              // input channels [0, c1)
@@ -48,11 +52,12 @@ struct DcFwd {
     int TH, TW;                                    // tile of logical outputs: TH * TW / 16 row blocks <= DC_NW * MI
     int IH, IW;                                    // input tile incl. halo
     const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
+    int wres, GT;                                  // wres 1: the whole packed filter stays in LDS for the block's lifetime; 0: GT tap slots are
+                                                   // staged at a time inside the tile loop (filters too big to sit beside the tile)
     float* wp;                                     // the filter re-packed for the LDS image: wp[slot][k / 4][n (NP)][k & 3], slots in tap-list
                                                    // order (dconv_pack_kernel, one tiny launch before the convolution): a block's staging
                                                    // is then a straight float4 copy instead of 25 * CIK * NP strided scalar gathers
     int N;                                         // real output channels (<= 16 * NB)
-    int GT;                                        // taps staged in LDS per pass
     int ncls; DcClass cls[4]; DcTap taps[DC_MAXTAPS];
     int osc, hout, wout;                           // physical output grid
     int tiles_y, tiles_x;
@@ -81,9 +86,12 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const DcFwd P, int NP, 
     (void)TPC;
 }
 
-// LDS: tile[IH*IW][CIP] | W4[GTK/4][NP][4] | toff[GTP]     (GTK = staged taps (padded to whole 16-k chunks) * CIK)
+// LDS: tile[IH*IW][CIP] | W4[wslots*CIK/4][NP][4]   (wslots = all class-padded tap slots when they fit beside the tile -- the
+// usual case: ONE barrier per block -- else GT slots staged at a time)
+// Row block rb = wv + DC_NW * mi: the 8 waves all stay busy (latency hiding) and, waves w and w + 4 sharing SIMD w % 4, the
+// matrix pipes are evenly loaded whenever the tile has a multiple of 4 row blocks.
 template <int CIK, int MI, int NB>
-__global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
+__global__ __launch_bounds__(DC_THREADS, 2) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
     constexpr int CIP = CIK == 4 ? 4 : CIK + 4;
     constexpr int NP = NB * 16;
     constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;          // taps per 16-k chunk
@@ -93,8 +101,11 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
     float* tile = smem;
     const int tile_floats = (P.IH * P.IW * CIP + 3) & ~3;
     float* W4 = smem + tile_floats;
-    const int gtp = (P.GT + TPC - 1) / TPC * TPC;           // staged tap slots (whole chunks)
-    int* toff = reinterpret_cast<int*>(W4 + gtp * CIK * NP);
+    auto stage = [&](int s0, int n) {                        // slots [s0, s0 + n) of the packed filter -> W4[0 ...)
+        const float4* src = reinterpret_cast<const float4*>(P.wp) + (int64_t)s0 * (CIK / 4) * NP;
+        float4* dst = reinterpret_cast<float4*>(W4);
+        for (int i = tid; i < n * (CIK / 4) * NP; i += DC_THREADS) dst[i] = src[i];
+    };
 
     int b = blockIdx.x;
     const int txi = b % P.tiles_x; b /= P.tiles_x;
@@ -103,7 +114,8 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
     const int ty0 = tyi * P.TH, tx0 = txi * P.TW;
     const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
 
-    // ---- input halo tile -> LDS (zero outside the image)
+    // ---- filter (when resident) and input halo tile -> LDS, all loads in flight together
+    if (P.wres) stage(0, nslots);
     if constexpr (CIK == 4) {
         const float* src = P.x1 + (int64_t)img * P.hin * P.win * 3;
         const int rowf = P.IW * 3;
@@ -132,82 +144,83 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
         }
     }
 
-    // this wave's rows: row block rb = wv * MI + mi -> logical pixel (ty, tx0l + l15)
     const int rbw = P.TW >> 4;                               // row blocks per tile row
-    const int nrb = P.TH * rbw;                              // row blocks of the tile (<= DC_NW * MI; the other waves only keep the barriers)
+    const int nrb = P.TH * rbw;                              // row blocks of the tile (<= DC_NW * MI)
     int abase[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int rb = wv * MI + mi, ty = rb / rbw, tx = (rb - ty * rbw) * 16 + l15;
+        const int rb = wv + DC_NW * mi, ty = rb / rbw, tx = (rb - ty * rbw) * 16 + l15;
         abase[mi] = rb < nrb ? ((P.S * ty) * P.IW + P.S * tx) * CIP : 0;
     }
-    const bool active = wv * MI < nrb;
+    const bool active = wv < nrb;
+    if (P.wres) __syncthreads();                             // tile + filter visible
 
     for (int ci = 0; ci < P.ncls; ++ci) {
-        const DcClass cl = P.cls[ci];
+        DcClass cl;                                          // (static indices: a dynamic one would put the argument struct in scratch)
+        switch (ci) { case 0: cl = P.cls[0]; break; case 1: cl = P.cls[1]; break; case 2: cl = P.cls[2]; break; default: cl = P.cls[3]; break; }
         f32x4 acc[MI][NB];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int t0 = 0; t0 < cl.ntaps; t0 += P.GT) {
-            const int nt = cl.ntaps - t0 < P.GT ? cl.ntaps - t0 : P.GT;
-            const int ntp = (nt + TPC - 1) / TPC * TPC;
-            __syncthreads();                                 // tile complete / previous stage consumed
-            // ---- stage the filter taps [t0, t0 + nt) of this class: W4[(e*CIK + k) / 4][n][k & 3], already in that order in wp
-            {
-                const float4* src = reinterpret_cast<const float4*>(P.wp) + (int64_t)(cl.pslot0 + t0) * (CIK / 4) * NP;
-                float4* dst = reinterpret_cast<float4*>(W4);
-                for (int i = tid; i < ntp * (CIK / 4) * NP; i += DC_THREADS) dst[i] = src[i];
+        const int ntp_all = (cl.ntaps + TPC - 1) / TPC * TPC;
+        const int gts = P.wres ? ntp_all : P.GT;
+        for (int t0 = 0; t0 < ntp_all; t0 += gts) {
+            const int ntp = ntp_all - t0 < gts ? ntp_all - t0 : gts;
+            if (!P.wres) {
+                __syncthreads();                             // tile complete / the previous stage's fragments consumed
+                stage(cl.pslot0 + t0, ntp);
+                __syncthreads();
             }
-            for (int e = tid; e < ntp; e += DC_THREADS) {
-                const DcTap tp = P.taps[cl.tap0 + t0 + (e < nt ? e : 0)];
-                toff[e] = (tp.dy * P.IW + tp.dx) * CIP;
-            }
-            __syncthreads();
-
             const int nchunks = active ? ntp / TPC * CPT : 0;
-            // software pipeline: the LDS reads of chunk c + 1 (tap offset -> A / B fragments, a dependent chain of two LDS
-            // latencies) are issued before the 4 * MI * NB MFMAs of chunk c
+            const int kW = P.wres ? (cl.pslot0 + t0) * CIK : 0;          // LDS-K coordinate of this stage's first slot
+            const int k0 = t0 * CIK + 4 * kg;                            // class-K coordinate of this lane's first k
             float4 a4[2][MI], b4[2][NB];
             auto fetch = [&](int c, int buf) {
-                const int k16 = 16 * c + 4 * kg;              // this lane's first k of the chunk, in staged-K coordinates
-                const int e = k16 / CIK, kin = k16 - e * CIK;
-                const int to = toff[e] + kin;
+                const int k16 = k0 + 16 * c;
+                int e = k16 / CIK;
+                const int kin = k16 - e * CIK;
+                e = e < cl.ntaps ? e : cl.ntaps - 1;                     // padded slots: any valid address (their filter rows are zero)
+                const int q = (e * cl.mdiv) >> 8, r = e - q * cl.ntx;
+                const int to = ((cl.dy0 + cl.sgn * q) * P.IW + cl.dx0 + cl.sgn * r) * CIP + kin;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) a4[buf][mi] = *reinterpret_cast<const float4*>(&tile[abase[mi] + to]);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) b4[buf][nb] = *reinterpret_cast<const float4*>(&W4[((4 * c + kg) * NP + nb * 16 + l15) * 4]);
+                for (int nb = 0; nb < NB; ++nb)
+                    b4[buf][nb] = *reinterpret_cast<const float4*>(&W4[((kW / 4 + 4 * c + kg) * NP + nb * 16 + l15) * 4]);
             };
             auto mma = [&](int buf) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int tt = 0; tt < 4; ++tt) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const float av = t == 0 ? a4[buf][mi].x : t == 1 ? a4[buf][mi].y : t == 2 ? a4[buf][mi].z : a4[buf][mi].w;
+                        const float av = tt == 0 ? a4[buf][mi].x : tt == 1 ? a4[buf][mi].y : tt == 2 ? a4[buf][mi].z : a4[buf][mi].w;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) {
-                            const float bv = t == 0 ? b4[buf][nb].x : t == 1 ? b4[buf][nb].y : t == 2 ? b4[buf][nb].z : b4[buf][nb].w;
+                            const float bv = tt == 0 ? b4[buf][nb].x : tt == 1 ? b4[buf][nb].y : tt == 2 ? b4[buf][nb].z : b4[buf][nb].w;
                             acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
                         }
                     }
                 }
             };
-            if (nchunks > 0) fetch(0, 0);
-            for (int c = 0; c < nchunks; c += 2) {
-                if (c + 1 < nchunks) fetch(c + 1, 1);
-                mma(0);
-                if (c + 1 < nchunks) {
-                    if (c + 2 < nchunks) fetch(c + 2, 0);
+            // software pipeline, branch-free in the steady state: fragments of chunk c + 1 are read before the MFMAs of chunk c
+            if (nchunks > 0) {
+                fetch(0, 0);
+                int c = 0;
+                for (; c + 2 < nchunks; c += 2) {
+                    fetch(c + 1, 1);
+                    mma(0);
+                    fetch(c + 2, 0);
                     mma(1);
                 }
+                if (c + 1 < nchunks) { fetch(c + 1, 1); mma(0); mma(1); }
+                else mma(0);
             }
         }
         // ---- epilogue of this class.  D: col = l15, row = 4 * kg + r
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const int rb = wv * MI + mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
+            const int rb = wv + DC_NW * mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
             const int y = ty0 + ty;
             if (rb >= nrb || y >= P.hlog) continue;
 #pragma unroll
@@ -223,6 +236,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P) {
             }
         }
     }
+    (void)ntiles;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,31 +338,37 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
             }
         }
         __syncthreads();
-        // ---- K loop over the tile's pixels, 16 per chunk: lane kg takes pixels 16c + 4kg + t
-        for (int c = 0; c < npix; c += 16) {
+        // ---- K loop over the tile's pixels, 16 per chunk: lane kg takes pixels 16c + 4kg + t.  Software-pipelined: the LDS
+        // reads of chunk c + 1 are issued before the MFMAs of chunk c.
+        float av[2][RBW][4], bv[2][NB][4];
+        auto fetch = [&](int c, int buf) {
             const int p0 = c + 4 * kg;
-            int pb[4], ps[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const int p = p0 + tt, ty = p >> P.tw_sh, tx = p - (ty << P.tw_sh);
-                pb[tt] = ((P.S * ty) * P.IW + P.S * tx) * CAP;
-                ps[tt] = p * CBP;
+                const int pbig = ((P.S * ty) * P.IW + P.S * tx) * CAP, psm = p * CBP;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bv[buf][nb][tt] = smallt[psm + nb * 16 + l15];
+#pragma unroll
+                for (int rb = 0; rb < RBW; ++rb) av[buf][rb][tt] = bigt[pbig + aoff[rb]];
             }
-            float bv[NB][4];
+        };
+        auto mma = [&](int buf) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
+            for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) bv[nb][tt] = smallt[ps[tt] + nb * 16 + l15];
-#pragma unroll
-            for (int rb = 0; rb < RBW; ++rb) {
-                float av[4];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt) av[tt] = bigt[pb[tt] + aoff[rb]];
-#pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tt], bv[nb][tt], acc[rb][nb], 0, 0, 0);
+                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rb][tt], bv[buf][nb][tt], acc[rb][nb], 0, 0, 0);
+        };
+        fetch(0, 0);
+        for (int c = 0; c < npix; c += 32) {
+            if (c + 16 < npix) fetch(c + 16, 1);
+            mma(0);
+            if (c + 16 < npix) {
+                if (c + 32 < npix) fetch(c + 32, 0);
+                mma(1);
             }
         }
     }

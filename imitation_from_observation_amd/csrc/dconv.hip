@@ -13,26 +13,35 @@ constexpr int LDS_BUDGET = 150 * 1024;      // of the 160 KiB per CU: one block 
 int cik_of(int CI) { return CI == 3 ? 4 : CI <= 8 ? 8 : CI <= 16 ? 16 : CI <= 32 ? 32 : 64; }
 
 template <int CIK, int MI>
-void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds) {
+void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds, int ntiles, int nslots) {
 #define DC_CASE(nb)                                                                                                          \
     case nb: {                                                                                                               \
         static bool raised = false;                                                                                          \
         if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET + 8192); raised = true; } \
-        hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, nb>), grid, dim3(DC_THREADS), lds, s, P);                              \
+        hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, nb>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);                              \
         break;                                                                                                               \
     }
-    switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
+    if constexpr (MI <= 2) {
+        switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
+    } else {
+        switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) default: break; }      // MI 3 / 4 with 8 column blocks would spill; never chosen
+    }
 #undef DC_CASE
 }
 
 template <int CIK>
-void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, dim3 grid, size_t lds) {
-    if (MI == 4) launch_fwd_nb<CIK, 4>(s, P, NB, grid, lds);
-    else if (MI == 3) launch_fwd_nb<CIK, 3>(s, P, NB, grid, lds);
-    else if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds);
-    else launch_fwd_nb<CIK, 1>(s, P, NB, grid, lds);
+void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, dim3 grid, size_t lds, int ntiles, int nslots) {
+    if (MI == 4) launch_fwd_nb<CIK, 4>(s, P, NB, grid, lds, ntiles, nslots);
+    else if (MI == 3) launch_fwd_nb<CIK, 3>(s, P, NB, grid, lds, ntiles, nslots);
+    else if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds, ntiles, nslots);
+    else launch_fwd_nb<CIK, 1>(s, P, NB, grid, lds, ntiles, nslots);
 }
 }  // namespace
+
+// measurement hook (tools/dconv_bench.hip): force the tile of the next launches; 0 = automatic
+int g_dc_force[3] = {0, 0, 0};       // TH, TW, MI
+void dconv_force_tile(int th, int tw, int mi) { g_dc_force[0] = th; g_dc_force[1] = tw; g_dc_force[2] = mi; }
+int g_dc_last[4] = {0, 0, 0, 0};     // TH, TW, MI, GT of the last forward launch
 
 bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 32 || CI == 64) && N >= 1 && N <= 128; }
 
@@ -43,12 +52,21 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     int NB = (P.N + 15) / 16;
     NB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
     const int NP = NB * 16, TPC = CIK >= 16 ? 1 : 16 / CIK;
-    // tile: TW = the logical row (16 / 32 / 64 wide grids) capped at 32; TH = the divisor of hlog that fills the 8 * MI row
-    // blocks best within the LDS budget (a tile of fewer row blocks leaves waves idle but multiplies nothing extra)
+    // the filter in the LDS image's order: classes padded to whole 16-k chunks
+    int nslots = 0, maxt = 0;
+    for (int c = 0; c < P.ncls; ++c) {
+        P.cls[c].pslot0 = nslots;
+        const int ntp = (P.cls[c].ntaps + TPC - 1) / TPC * TPC;
+        nslots += ntp;
+        maxt = ntp > maxt ? ntp : maxt;
+    }
+    const size_t wall = (size_t)nslots * CIK * NP * 4 + (size_t)nslots * 4 + 64;
+    const size_t wmin = (size_t)4 * TPC * CIK * NP * 4 + 256;     // staged mode: at least four chunks of taps at a time
     // tile: TW in {16, 32, 64} (<= the logical row), TH rows; MI = row blocks per wave.  Cost model: the matrix pipes are
     // per SIMD and wave w sits on SIMD w % 4, so a tile takes the time of its busiest SIMD; scored as useful row blocks per
-    // (4 x busiest SIMD), times the share of real rows in ragged last tiles, times the halo overhead of the input tile.
-    int best_th = 1, best_mi = 1, best_tw = 16;
+    // (4 x busiest SIMD), times the share of real rows in ragged last tiles, times the halo overhead of the input tile,
+    // with a penalty when the filter cannot stay resident beside the tile (it is then re-staged per tile, with barriers).
+    int best_th = 1, best_mi = 1, best_tw = 16, best_res = 1;
     double best = -1;
     const int mi_max = NB >= 8 ? 2 : 4;                       // accumulators: MI * NB * 4 registers
     for (int tw = 16; tw <= 64 && tw <= (P.wlog + 15) / 16 * 16; tw *= 2)
@@ -58,18 +76,24 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
                 if (nrb > DC_NW * mi) break;
                 const int ih = P.S * (th - 1) + span, iw = P.S * (tw - 1) + span;
                 const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
-                const size_t need = tile + (size_t)TPC * CIK * NP * 4 + 256;
-                if (need > (size_t)LDS_BUDGET) break;
-                const bool two = 2 * (need + (size_t)3 * TPC * CIK * NP * 4) <= (size_t)LDS_BUDGET;   // two blocks per CU (with a few taps staged): one's staging under the other's MFMAs
+                const bool res = tile + wall <= (size_t)LDS_BUDGET;
+                if (!res && tile + wmin > (size_t)LDS_BUDGET) break;
                 int load[4] = {0, 0, 0, 0};
-                for (int w = 0; w * mi < nrb; ++w) load[w & 3] += nrb - w * mi < mi ? nrb - w * mi : mi;
+                for (int rb = 0; rb < nrb; ++rb) load[rb & 3] += 1;                   // row block rb runs on wave rb % 8, i.e. SIMD rb % 4
                 int busiest = 1;
                 for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
                 const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
                 const double eff = (double)nrb / (4.0 * busiest) * ((double)P.hlog * P.wlog / ((double)tiles_y * th * tiles_x * tw)) *
-                                   ((double)(th * tw * P.S * P.S) / (ih * iw)) * (mi >= 2 ? 1.0 : 0.85) * (two ? 1.0 : 0.75);   // MI = 1 re-reads B per row block
-                if (eff > best) { best = eff; best_th = th; best_mi = mi; best_tw = tw; }
+                                   ((double)(th * tw * P.S * P.S) / (ih * iw)) * (mi >= 2 ? 1.0 : 0.9) * (res ? 1.0 : 0.7) *
+                                   (nrb >= 8 ? 1.0 : 0.8) *                         // few active waves hide little latency
+                                   (2 * (tile + (res ? wall : wmin)) <= (size_t)LDS_BUDGET ? 1.0 : 0.85);  // two blocks per CU: one's loads under the other's MFMAs
+                if (eff > best) { best = eff; best_th = th; best_mi = mi; best_tw = tw; best_res = res; }
             }
+    if (g_dc_force[0]) {
+        best_th = g_dc_force[0]; best_tw = g_dc_force[1]; best_mi = g_dc_force[2];
+        const int ih = P.S * (best_th - 1) + span, iw = P.S * (best_tw - 1) + span;
+        best_res = (size_t)((ih * iw * CIP + 3) & ~3) * 4 + wall <= (size_t)LDS_BUDGET;
+    }
     P.TW = best_tw;
     P.TH = best_th;
     const int MI = best_mi;
@@ -78,20 +102,18 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     P.tiles_y = (P.hlog + P.TH - 1) / P.TH;
     P.tiles_x = (P.wlog + P.TW - 1) / P.TW;
     const size_t tile = (size_t)((P.IH * P.IW * CIP + 3) & ~3) * 4;
-    int maxt = 0;
-    for (int c = 0; c < P.ncls; ++c) maxt = P.cls[c].ntaps > maxt ? P.cls[c].ntaps : maxt;
-    size_t wbudget = (size_t)LDS_BUDGET - tile - 256;
-    if (2 * (tile + 256 + (size_t)4 * TPC * CIK * NP * 4) <= (size_t)LDS_BUDGET) wbudget = (size_t)LDS_BUDGET / 2 - tile - 256;   // leave room for a second block
-    int gt = (int)(wbudget / ((size_t)CIK * NP * 4));
-    gt = gt / TPC * TPC;
-    if (gt > (maxt + TPC - 1) / TPC * TPC) gt = (maxt + TPC - 1) / TPC * TPC;
-    if (gt < TPC) gt = TPC;
+    P.wres = best_res;
+    int gt = nslots;
+    if (!P.wres) {
+        gt = (int)(((size_t)LDS_BUDGET - tile - 256) / ((size_t)CIK * NP * 4)) / TPC * TPC;
+        if (gt > maxt) gt = maxt;
+        if (gt < TPC) gt = TPC;
+    }
     P.GT = gt;
-    const size_t lds = tile + (size_t)gt * CIK * NP * 4 + (size_t)(gt + 4) * 4;
-    const dim3 grid((unsigned)(P.nimg * P.tiles_y * P.tiles_x));
-    // the filter in the LDS image's order (classes padded to whole 16-k chunks)
-    int nslots = 0;
-    for (int c = 0; c < P.ncls; ++c) { P.cls[c].pslot0 = nslots; nslots += (P.cls[c].ntaps + TPC - 1) / TPC * TPC; }
+    g_dc_last[0] = P.TH; g_dc_last[1] = P.TW; g_dc_last[2] = MI; g_dc_last[3] = P.wres ? -nslots : gt;
+    const size_t lds = tile + (size_t)(P.wres ? nslots : gt) * CIK * NP * 4 + (size_t)(nslots + 4) * 4;
+    const int ntiles = P.nimg * P.tiles_y * P.tiles_x;
+    const dim3 grid((unsigned)ntiles);
     {
         const int total = nslots * CIK * NP;
         const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
@@ -104,11 +126,11 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
         }
     }
     switch (CIK) {
-        case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds); break;
-        case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds); break;
-        case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds); break;
-        case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds); break;
-        default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds); break;
+        case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+        case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+        case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+        case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+        default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
     }
 }
 
@@ -116,7 +138,7 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
 void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
     P.S = stride; P.y_org = -pad; P.x_org = -pad;
     P.hlog = P.hout = P.hin / stride; P.wlog = P.wout = P.win / stride; P.osc = 1;
-    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0};
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0, 5, 52, 0, 0, 1};
     for (int ky = 0; ky < 5; ++ky)
         for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)ky, (int16_t)kx, (int16_t)(ky * 5 + kx), 0};
     dconv_launch(s, P, 5);
@@ -126,7 +148,7 @@ void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
 void dconv_convt1(hipStream_t s, DcFwd P) {
     P.S = 1; P.y_org = -2; P.x_org = -2;
     P.hlog = P.hout = P.hin; P.wlog = P.wout = P.win; P.osc = 1;
-    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0};
+    P.ncls = 1; P.cls[0] = DcClass{0, 25, 0, 0, 0, 5, 52, 4, 4, -1};
     for (int ky = 0; ky < 5; ++ky)
         for (int kx = 0; kx < 5; ++kx) P.taps[ky * 5 + kx] = DcTap{(int16_t)(4 - ky), (int16_t)(4 - kx), (int16_t)(ky * 5 + kx), 0};
     dconv_launch(s, P, 5);
@@ -143,7 +165,7 @@ void dconv_convt2(hipStream_t s, DcFwd P) {
         const int py = c >> 1, px = c & 1;
         const int pary = (py + 1) & 1, parx = (px + 1) & 1, nty = (5 - pary + 1) / 2, ntx = (5 - parx + 1) / 2;
         const int oy = (py + 1 - pary) / 2, ox = (px + 1 - parx) / 2;
-        P.cls[c] = DcClass{nt, nty * ntx, py, px, 0};
+        P.cls[c] = DcClass{nt, nty * ntx, py, px, 0, ntx, ntx == 2 ? 128 : 86, oy + 1, ox + 1, -1};
         for (int sy = 0; sy < nty; ++sy)
             for (int sx = 0; sx < ntx; ++sx)
                 P.taps[nt++] = DcTap{(int16_t)(oy - sy + 1), (int16_t)(ox - sx + 1), (int16_t)((pary + 2 * sy) * 5 + parx + 2 * sx), 0};

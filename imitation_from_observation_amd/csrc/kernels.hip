@@ -327,6 +327,41 @@ void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// The reward hook's per-frame cost (rllab/sampler/base.py:243-249): for frame row j of a batch of paths,
+//   cost_j = sum_f (means[j % bs][f] - feat[j][f])^2  +  scale * sum_e (imgs[j % bs][e] - x[j][e])^2
+// ('nofeat' keeps only the image term, 'noimage' only the feature term).  One block per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void reward_cost_kernel(const float* __restrict__ feat, int ldf, int F, const float* __restrict__ x,
+                                                               int64_t npi, const float* __restrict__ means, const float* __restrict__ imgs,
+                                                               int bs, float scale, int ablation, float* __restrict__ costs) {
+    __shared__ float sh[4];
+    const int j = blockIdx.x, jj = j % bs;
+    float cf = 0.f, ci = 0.f;
+    if (ablation != 1) {
+        const float* a = means + (int64_t)jj * F;
+        const float* b = feat + (int64_t)j * ldf;
+        for (int f = threadIdx.x; f < F; f += NTHREADS) { const float d = a[f] - b[f]; cf += d * d; }
+    }
+    if (ablation != 2) {
+        const float* a = imgs + (int64_t)jj * npi;
+        const float* b = x + (int64_t)j * npi;
+        for (int64_t e = (int64_t)threadIdx.x * 4; e < npi; e += NTHREADS * 4) {
+            const float4 u = ldg4(a + e), v = ldg4(b + e);
+            const float d0 = u.x - v.x, d1 = u.y - v.y, d2 = u.z - v.z, d3 = u.w - v.w;
+            ci += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+    }
+    const float rf = block_sum(cf, sh), ri = block_sum(ci, sh);
+    if (threadIdx.x == 0) costs[j] = ablation == 0 ? rf + scale * ri : ablation == 1 ? scale * ri : rf;
+}
+
+void reward_costs(hipStream_t s, const float* feat, int ldf, int F, const float* x, int64_t npi, const float* means, const float* imgs,
+                  int bs, int nframes, float scale, int ablation, float* costs) {
+    hipLaunchKernelGGL(reward_cost_kernel, dim3((unsigned)nframes), dim3(NTHREADS), 0, s, feat, ldf, F, x, npi, means, imgs, bs, scale,
+                       ablation, costs);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Bias gradient: column sums of a row-major [rows, C] gradient, HBM-bound.  Stage 1: float4 columns;
 // a block covers min(C/4, 256) float4-columns x (256 / that) row lanes and walks its row slab with
 // coalesced full-row reads; row lanes are combined through LDS.  Stage 2 adds the slabs in fixed

@@ -46,7 +46,7 @@ void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, 
 // narrow-channel direct convolutions (dconv.h / dconv.hip).  P carries tensors, channel counts, filter and epilogue; the
 // launchers fill the tap tables, tiles and LDS split.  dconv_ok: the channel counts the kernels are instantiated for.
 bool dconv_ok(int CI, int N);
-constexpr int64_t DC_WPACK_FLOATS = 40ll * 64 * 128;        // P.wp: <= 37 class-padded tap slots x 64 k x 128 n
+constexpr int64_t DC_WPACK_FLOATS = 40ll * 64 * 128 + 64;   // P.wp: <= 37 class-padded tap slots x 64 k x 128 n, then their tile offsets
 void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad);        // conv2d 5x5 SAME (also: input gradient of conv2d_transpose)
 void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 1 (also: input gradient of a stride-1 conv2d)
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
@@ -86,6 +86,11 @@ void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t n
 constexpr int LOSS_BLOCKS = 512;
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
             const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real = 0);
+
+// per-frame reward cost (rllab/sampler/base.py:243-249): costs[j] = |means[j % bs] - feat[j]|^2 + scale * |imgs[j % bs] - x[j]|^2
+// (ablation 1: image term only, 2: feature term only)
+void reward_costs(hipStream_t s, const float* feat, int ldf, int F, const float* x, int64_t npi, const float* means, const float* imgs,
+                  int bs, int nframes, float scale, int ablation, float* costs);
 
 // db[c] = sum_rows x[row][c], deterministic two-stage; scratch >= COLSUM_SPLITS * max(C, 4) floats
 constexpr int COLSUM_SPLITS = 512;

@@ -108,6 +108,8 @@ class TranslatorReward:
                 fsum, isum = flat[:fsum.size].reshape(fsum.shape), flat[fsum.size:].reshape(isum.shape)
             self.means.append((fsum / nvid).astype(np.float32))            # np.mean(tfeats, axis=0), base.py:221
             self.imgs.append((isum / nvid).astype(np.float32))             # np.mean(timgs, axis=0), base.py:222
+            if hasattr(self.tr, "reward_set_cache"):                       # the cost is then computed on the device, next to the encoder
+                self.tr.reward_set_cache(vp, self.means[vp], self.imgs[vp])
         return self
 
     # ------------------------------------------------------------------ base.py:232-252
@@ -139,10 +141,14 @@ class TranslatorReward:
             for p0 in range(0, len(paths), per_call):
                 grp = range(p0, min(len(paths), p0 + per_call))
                 u8 = np.concatenate([np.stack([fr[vp] for fr in frames[p]]).astype(np.uint8) for p in grp])
-                feats, x = self.tr.encode(u8)                              # [input_z, image_trans[0]], base.py:234-235
+                if hasattr(self.tr, "reward_costs"):
+                    # encoder + cost on the device: only the [paths, bs] costs cross PCIe (not the 4-bytes-per-pixel frames)
+                    dev = self.tr.reward_costs(vp, u8, self.scale, self.ablation_type)
+                else:
+                    feats, x = self.tr.encode(u8)                          # [input_z, image_trans[0]], base.py:234-235
                 for k, p in enumerate(grp):
                     sl = slice(k * bs, (k + 1) * bs)
-                    c = self._costs_from(feats[sl], x[sl], vp)
+                    c = dev[k] if hasattr(self.tr, "reward_costs") else self._costs_from(feats[sl], x[sl], vp)
                     # 'None' accumulates over viewpoints (costs += ...); the ablations overwrite (costs = ...)
                     costs[p] = costs[p] + c if self.ablation_type == "None" else c
         return costs

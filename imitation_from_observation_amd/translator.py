@@ -248,6 +248,28 @@ class Translator:
         self._ck(self._lib.ctx_encode(self._h, _up(fr), B, _fp(feat), _fp(f32) if return_frames else None))
         return feat, f32
 
+    # ------------------------------------------------------------------ reward hook on the device (base.py:232-249)
+    ABLATIONS = {"None": 0, "nofeat": 1, "noimage": 2}
+
+    def reward_set_cache(self, vp, means, imgs):
+        """Keep the demo cache of viewpoint vp (means [bs, featsize], imgs [bs,H,W,3]; base.py:221-222) on the device."""
+        means = _f32(means)
+        bs = means.shape[0]
+        means, imgs = _f32(means, (bs, self.featsize)), _f32(imgs, (bs, self.H, self.W, 3))
+        self._ck(self._lib.ctx_reward_set_cache(self._h, int(vp), _fp(means), _fp(imgs), bs))
+        self._reward_bs = bs
+
+    def reward_costs(self, vp, frames, scale, ablation_type="None"):
+        """frames uint8 [npaths*bs,H,W,3] -> costs f32 [npaths, bs] of base.py:243-249, computed next to the encoder's output."""
+        fr = _u8(frames)
+        bs = self._reward_bs
+        if fr.ndim != 4 or fr.shape[1:] != (self.H, self.W, 3) or fr.shape[0] % bs:
+            raise ValueError(f"frames must be [npaths*{bs},{self.H},{self.W},3], got {fr.shape}")
+        npaths = fr.shape[0] // bs
+        costs = np.empty((npaths, bs), np.float32)
+        self._ck(self._lib.ctx_reward_costs(self._h, int(vp), _up(fr), npaths, float(scale), self.ABLATIONS[ablation_type], _fp(costs)))
+        return costs
+
     # ------------------------------------------------------------------ training
     def _triple(self, src, ctx, tgt):
         src = _f32(src)

@@ -129,6 +129,15 @@ int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ct
                       float* pred, float* feat);
 int ctx_encode_f32(ctx_handle* h, const float* frames, int B, float* feat);
 
+/* The per-path cost of the reward hook computed where the frames already are (base.py:232-249), several paths per call:
+ * ctx_reward_set_cache keeps, per viewpoint vp, the demo cache  means [bs, featsize] (= self.means[vp]) and  imgs [bs,H,W,3]
+ * (= self.imgs[vp])  on the device;  ctx_reward_costs encodes  frames [npaths*bs,H,W,3] uint8 (npaths rollouts of bs rendered
+ * frames) and returns  costs[p*bs + j] = sum((means[j] - input_z[p,j])^2) + scale * sum((imgs[j] - image_trans[0][p,j])^2)
+ * (ablation 0 = "None"; 1 = "nofeat": image term only; 2 = "noimage": feature term only).  Only npaths*bs floats come back
+ * over PCIe instead of the preprocessed frames (49 MB at 40 paths). */
+int ctx_reward_set_cache(ctx_handle* h, int vp, const float* means, const float* imgs, int bs);
+int ctx_reward_costs(ctx_handle* h, int vp, const uint8_t* frames, int npaths, float scale, int ablation, float* costs);
+
 /* ---- training --------------------------------------------------------------------------------- */
 /* src/ctx/tgt [B,H,W,3] f32 in [-1,1] (tfinput[0], [1], [2]).  scalars = {loss, simloss, recon1,
  * recon2} of the forward pass before the update.  Adam: TF defaults b1 .9, b2 .999, eps 1e-8. */

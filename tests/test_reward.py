@@ -292,3 +292,33 @@ def test_oursinception_hook_matches_oracle_composition():
     np.testing.assert_allclose(c, cref, rtol=1e-3)
     for a, b in zip(paths2, paths):
         np.testing.assert_allclose(a["rewards"], b["rewards"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["skipnew", "real"])
+def test_device_cost_kernel_equals_the_host_formula(variant):
+    """ctx_reward_costs (encoder + cost next to its output, only the costs cross PCIe) == base.py:243-249 evaluated on the host
+    from ctx_encode's fetches, for the three runnable ablations; ContextAEReal keeps its codes at a padded row stride."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import CtxError, Translator
+    rng = np.random.default_rng(12)
+    Hh, Ww, F = (16, 16, 32) if variant == "skipnew" else (12, 16, 100)
+    bs, npaths = 25, 3
+    with Translator(Hh, Ww, 32, F, max_batch=bs * npaths, variant=variant) as tr:
+        tr.init_params(3)
+        means = rng.standard_normal((bs, F)).astype(np.float32)
+        imgs = rng.uniform(-1, 1, (bs, Hh, Ww, 3)).astype(np.float32)
+        frames = rng.integers(0, 256, (bs * npaths, Hh, Ww, 3), dtype=np.uint8)
+        with pytest.raises(CtxError):
+            tr._reward_bs = bs
+            tr.reward_costs(0, frames, 0.5)                       # no cache yet
+        tr.reward_set_cache(0, means, imgs)
+        feats, x = tr.encode(frames)
+        for abl in ("None", "nofeat", "noimage"):
+            hook = TranslatorReward(tr, 1, 0.5, ablation_type=abl)
+            hook.means, hook.imgs = [means], [imgs]
+            want = np.stack([hook._costs_from(feats[k * bs:(k + 1) * bs], x[k * bs:(k + 1) * bs], 0) for k in range(npaths)])
+            got = tr.reward_costs(0, frames, 0.5, abl)
+            np.testing.assert_allclose(got, want, rtol=2e-5)

@@ -1,0 +1,119 @@
+// Development tool: times the narrow-channel direct convolutions (csrc/dconv.hip) on ContextAEReal's layer shapes at
+// B = 256, 36x64, for every legal tile (TH, TW, MI), next to the automatic choice.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I imitation_from_observation_amd/csrc tools/dconv_bench.hip \
+//         imitation_from_observation_amd/csrc/dconv.hip -o tools/dconv_bench.bin && tools/dconv_bench.bin
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "launch.h"
+
+namespace ctx {
+void dconv_force_tile(int th, int tw, int mi);
+extern int g_dc_last[4];
+}
+using namespace ctx;
+
+struct Layer { const char* name; int kind; int CI, c1, nimg, hin, win, S, N; };   // kind 0 conv, 1 convt1, 2 convt2
+
+static float* dalloc(size_t n, float val) {
+    float* p;
+    (void)hipMalloc(&p, n * 4);
+    std::vector<float> h(n, val);
+    for (size_t i = 0; i < n; ++i) h[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
+    (void)hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice);
+    return p;
+}
+
+int main(int argc, char** argv) {
+    const int only = argc > 1 ? atoi(argv[1]) : -1;      // one layer, automatic tile, three launches: for rocprofv3 --pmc
+    const int B = 256;
+    const Layer layers[] = {
+        {"h0 fwd      F s1  3->32  36x64 x768", 0, 3, 3, 3 * B, 36, 64, 1, 32},
+        {"h1 fwd      F s2 32->16  36x64 x768", 0, 32, 32, 3 * B, 36, 64, 2, 16},
+        {"h2 fwd      F s1 16->16  18x32 x768", 0, 16, 16, 3 * B, 18, 32, 1, 16},
+        {"h3 fwd      F s2 16->8   18x32 x768", 0, 16, 16, 3 * B, 18, 32, 2, 8},
+        {"d_h4 dx     F s1  3->64  36x64 x512", 0, 3, 3, 2 * B, 36, 64, 1, 64},
+        {"d_h3 dx     F s2 32->32  36x64 x512", 0, 32, 32, 2 * B, 36, 64, 2, 32},
+        {"d_h2 dx     F s1 16->32  18x32 x512", 0, 16, 16, 2 * B, 18, 32, 1, 32},
+        {"d_h1 dx     F s2 16->16  18x32 x512", 0, 16, 16, 2 * B, 18, 32, 2, 16},
+        {"d_h1 fwd    T s2 8|8->16  9x16 x512", 2, 16, 8, 2 * B, 9, 16, 2, 16},
+        {"d_h2 fwd    T s1 16|16->16 18x32x512", 1, 32, 16, 2 * B, 18, 32, 1, 16},
+        {"d_h3 fwd    T s2 16|16->32 18x32x512", 2, 32, 16, 2 * B, 18, 32, 2, 32},
+        {"h3 dx       T s2  8->16   9x16 x768", 2, 8, 8, 3 * B, 9, 16, 2, 16},
+        {"h2 dx       T s1 16->16  18x32 x768", 1, 16, 16, 3 * B, 18, 32, 1, 16},
+        {"h1 dx       T s2 16->32  18x32 x768", 2, 16, 16, 3 * B, 18, 32, 2, 32},
+    };
+    hipStream_t st;
+    (void)hipStreamCreate(&st);
+    float* x1 = dalloc((size_t)3 * B * 36 * 64 * 32, 0.f);
+    float* x2 = dalloc((size_t)B * 36 * 64 * 32, 0.f);
+    float* w = dalloc(25 * 64 * 128, 0.f);
+    float* bias = dalloc(128, 0.f);
+    float* out = dalloc((size_t)3 * B * 36 * 64 * 64, 0.f);
+    float* wp = dalloc(DC_WPACK_FLOATS, 0.f);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    int li = -1;
+    for (const Layer& L : layers) {
+        ++li;
+        if (only >= 0 && li != only) continue;
+        DcFwd P{};
+        P.x1 = x1; P.ld1 = L.c1; P.c1 = L.c1; P.CI = L.CI;
+        if (L.c1 < L.CI) { P.x2 = x2; P.ld2 = L.CI - L.c1; P.nmod2 = B; }
+        P.hin = L.hin; P.win = L.win; P.nimg = L.nimg; P.w = w; P.wmode = L.kind ? 1 : 0; P.N = L.N; P.wp = wp;
+        P.ep.out1 = out; P.ep.ld1 = L.N; P.ep.bias = bias; P.ep.lrelu = 1;
+        auto run = [&]() {
+            if (L.kind == 0) dconv_conv(st, P, L.S, L.S == 1 ? 2 : 1);
+            else if (L.kind == 1) dconv_convt1(st, P);
+            else dconv_convt2(st, P);
+        };
+        auto timeit = [&]() {
+            run();
+            if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) return -1.f;
+            (void)hipEventRecord(e0, st);
+            for (int i = 0; i < 10; ++i) run();
+            (void)hipEventRecord(e1, st);
+            (void)hipStreamSynchronize(st);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            return ms / 10;
+        };
+        const int hl = L.kind == 0 ? L.hin / L.S : L.hin, wl = L.kind == 0 ? L.win / L.S : L.win;
+        const double flops = 2.0 * L.nimg * (L.kind == 2 ? 4.0 * hl * wl * 6.25 : (double)hl * wl * 25) * L.CI * L.N;
+        dconv_force_tile(0, 0, 0);
+        if (only >= 0) { run(); run(); run(); (void)hipStreamSynchronize(st); return 0; }
+        const float t_auto = timeit();
+        printf("%s  auto: TH %d TW %d MI %d GT %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
+               flops / t_auto / 1e9);
+        struct R { int th, tw, mi; float ms; };
+        std::vector<R> rs;
+        for (int tw = 16; tw <= 64; tw *= 2) {
+            if (tw > (wl + 15) / 16 * 16) continue;
+            for (int mi = 1; mi <= 4; ++mi)
+                for (int th = 1; th <= 16; ++th) {
+                    const int nrb = th * tw / 16;
+                    if (nrb > 8 * mi || nrb <= 8 * (mi - 1) / 2) continue;          // skip tiles a smaller MI covers as well
+                    const int span = L.kind == 2 ? 3 : 5, S = L.kind == 0 ? L.S : 1;
+                    const int cik = L.CI == 3 ? 4 : L.CI, cip = cik == 4 ? 4 : cik + 4;
+                    const size_t tile = (size_t)(S * (th - 1) + span) * (S * (tw - 1) + span) * cip * 4;
+                    if (tile + 20000 > 150 * 1024) continue;
+                    if (mi > 2 && L.N > 64) continue;
+                    dconv_force_tile(th, tw, mi);
+                    const float ms = timeit();
+                    if (ms > 0) rs.push_back({th, tw, mi, ms});
+                }
+        }
+        for (int k = 0; k < 6 && !rs.empty(); ++k) {
+            size_t bi = 0;
+            for (size_t i = 1; i < rs.size(); ++i) if (rs[i].ms < rs[bi].ms) bi = i;
+            printf("      TH %2d TW %2d MI %d  %.3f ms  %.1f TF/s\n", rs[bi].th, rs[bi].tw, rs[bi].mi, rs[bi].ms, flops / rs[bi].ms / 1e9);
+            rs.erase(rs.begin() + bi);
+        }
+        fflush(stdout);
+    }
+    return 0;
+}
