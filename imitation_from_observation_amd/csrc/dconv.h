@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "igemm.h"
 
 namespace ctx {
@@ -52,8 +54,8 @@ struct DcFwd {
     int TH, TW;                                    // tile of logical outputs: TH * TW / 16 row blocks <= DC_NW * MI
     int IH, IW;                                    // input tile incl. halo
     const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
-    int wres, GT;                                  // wres 1: the whole packed filter stays in LDS for the block's lifetime; 0: GT tap slots are
-                                                   // staged at a time inside the tile loop (filters too big to sit beside the tile)
+    int n0, NPT;                                   // this launch computes output columns [n0, n0 + 16 * NB) (filters too big to sit in LDS beside
+                                                   // a tile are run as several column slices); NPT = column count of the packed image
     float* wp;                                     // the filter re-packed for the LDS image: wp[slot][k / 4][n (NP)][k & 3], slots in tap-list
                                                    // order (dconv_pack_kernel, one tiny launch before the convolution): a block's staging
                                                    // is then a straight float4 copy instead of 25 * CIK * NP strided scalar gathers
@@ -86,63 +88,146 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const DcFwd P, int NP, 
     (void)TPC;
 }
 
-// LDS: tile[IH*IW][CIP] | W4[wslots*CIK/4][NP][4]   (wslots = all class-padded tap slots when they fit beside the tile -- the
-// usual case: ONE barrier per block -- else GT slots staged at a time)
+// LDS: tile[IH*IW][CIP] | W4[nslots*CIK/4][NP][4] (the whole class-padded filter, resident for the block's lifetime).
+//
+// PERSISTENT blocks with a REGISTER-STAGED PREFETCH: a block walks tiles t = blockIdx.x, + gridDim.x, ...; while it runs the
+// MFMA loop of tile t out of LDS, the global loads of tile t + gridDim.x are already in flight into DC_PF registers per
+// thread (one float4 -- one float of the [pixel][3] tensors -- per slot), and are written to LDS after the loop.  The first
+// version staged each tile with a dependent load -> ds_write loop and one tile per block: 11 exposed HBM round trips per
+// tile, 24 us per block for 2.7 us of MFMA work (h1_conv of ContextAEReal: 0.43 ms for a 0.07 ms layer).
+// Out-of-image pixels are raw_buffer_loads at the out-of-range marker (the hardware returns zeros, no branch, no traffic).
 // Row block rb = wv + DC_NW * mi: the 8 waves all stay busy (latency hiding) and, waves w and w + 4 sharing SIMD w % 4, the
 // matrix pipes are evenly loaded whenever the tile has a multiple of 4 row blocks.
+constexpr int DC_PF = 12;
+typedef unsigned dc_u32x4 __attribute__((ext_vector_type(4)));
+
 template <int CIK, int MI, int NB>
-__global__ __launch_bounds__(DC_THREADS, 2) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
+__global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
     constexpr int CIP = CIK == 4 ? 4 : CIK + 4;
     constexpr int NP = NB * 16;
     constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;          // taps per 16-k chunk
     constexpr int CPT = CIK >= 16 ? CIK / 16 : 1;          // chunks per tap
+    constexpr int C4 = CIK / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
     float* tile = smem;
     const int tile_floats = (P.IH * P.IW * CIP + 3) & ~3;
     float* W4 = smem + tile_floats;
-    auto stage = [&](int s0, int n) {                        // slots [s0, s0 + n) of the packed filter -> W4[0 ...)
-        const float4* src = reinterpret_cast<const float4*>(P.wp) + (int64_t)s0 * (CIK / 4) * NP;
+
+    // ---- resident filter: columns [n0, n0 + NP) of the packed image wp[slot * CIK / 4 + kq][NPT][4]
+    {
+        const float4* src = reinterpret_cast<const float4*>(P.wp);
         float4* dst = reinterpret_cast<float4*>(W4);
-        for (int i = tid; i < n * (CIK / 4) * NP; i += DC_THREADS) dst[i] = src[i];
-    };
-
-    int b = blockIdx.x;
-    const int txi = b % P.tiles_x; b /= P.tiles_x;
-    const int tyi = b % P.tiles_y;
-    const int img = b / P.tiles_y;
-    const int ty0 = tyi * P.TH, tx0 = txi * P.TW;
-    const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
-
-    // ---- filter (when resident) and input halo tile -> LDS, all loads in flight together
-    if (P.wres) stage(0, nslots);
-    if constexpr (CIK == 4) {
-        const float* src = P.x1 + (int64_t)img * P.hin * P.win * 3;
-        const int rowf = P.IW * 3;
-        for (int i = tid; i < P.IH * rowf; i += DC_THREADS) {
-            const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            float v = 0.f;
-            if ((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win) v = src[((int64_t)gy * P.win + gx) * 3 + ch];
-            tile[(iy * P.IW + ix) * 4 + ch] = v;
-        }
-        for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) tile[i * 4 + 3] = 0.f;
-    } else {
-        constexpr int C4 = CIK / 4;
-        const float* s1 = P.x1 + (int64_t)img * P.hin * P.win * P.ld1;
-        const float* s2 = P.x2 ? P.x2 + (int64_t)(img % P.nmod2) * P.hin * P.win * P.ld2 : nullptr;
-        for (int i = tid; i < P.IH * P.IW * C4; i += DC_THREADS) {
-            const int pi = i / C4, c = (i - pi * C4) * 4;
-            const int iy = pi / P.IW, ix = pi - iy * P.IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            float4 v = zero4();
-            if ((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win) {
-                const int64_t pix = (int64_t)gy * P.win + gx;
-                v = c < P.c1 ? ldg4(s1 + pix * P.ld1 + c) : ldg4(s2 + pix * P.ld2 + (c - P.c1));
+        const int total = nslots * C4 * NP;
+        for (int i0 = tid; i0 < total; i0 += 4 * DC_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * DC_THREADS, row = i / NP, n = i - row * NP;
+                v[u] = i < total ? src[(int64_t)row * P.NPT + P.n0 + n] : zero4();
             }
-            *reinterpret_cast<float4*>(&tile[pi * CIP + c]) = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (i0 + u * DC_THREADS < total) dst[i0 + u * DC_THREADS] = v[u];
         }
     }
+    if constexpr (CIK == 4) for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) tile[i * 4 + 3] = 0.f;   // the 4th channel is never loaded
+    // tab[g][kg]: byte offset, inside the tile, of (tap, first channel) that lane group kg multiplies in chunk g of the packed K
+    // order (tile-invariant: computed once here instead of ~40 ALU instructions per chunk in front of every ds_read)
+    int* tab = reinterpret_cast<int*>(W4 + (size_t)nslots * CIK * NP);
+    for (int ci = 0; ci < P.ncls; ++ci) {
+        DcClass cl;                                          // (static indices: a dynamic one would put the argument struct in scratch)
+        switch (ci) { case 0: cl = P.cls[0]; break; case 1: cl = P.cls[1]; break; case 2: cl = P.cls[2]; break; default: cl = P.cls[3]; break; }
+        const int g0 = cl.pslot0 * CIK / 16, ng = (cl.ntaps + TPC - 1) / TPC * CPT;
+        for (int i = tid; i < (ng + 1) * 4; i += DC_THREADS) {           // (+ 1: the entry the pipeline reads one chunk ahead)
+            const int k16 = (i >> 2) * 16 + 4 * (i & 3);
+            int e = k16 / CIK;
+            const int kin = k16 - e * CIK;
+            e = e < cl.ntaps ? e : cl.ntaps - 1;             // padded slots: any valid address (their filter rows are zero)
+            const int q = (e * cl.mdiv) >> 8, r = e - q * cl.ntx;
+            tab[g0 * 4 + i] = (((cl.dy0 + cl.sgn * q) * P.IW + cl.dx0 + cl.sgn * r) * CIP + kin) * 4;
+        }
+    }
+
+    const int ntile_e = CIK == 4 ? P.IH * P.IW * 3 : P.IH * P.IW * C4;      // elements (floats | float4s) of one input tile
+    const int rowf = P.IW * 3;
+    dc_u32x4 pf[CIK == 4 ? 1 : DC_PF];
+    unsigned pf1[CIK == 4 ? DC_PF : 1];
+    auto tile_org = [&](int t, int& img, int& ty0, int& tx0) {
+        const int txi = t % P.tiles_x; t /= P.tiles_x;
+        const int tyi = t % P.tiles_y;
+        img = t / P.tiles_y; ty0 = tyi * P.TH; tx0 = txi * P.TW;
+    };
+    auto issue = [&](int t) {                                // global loads of tile t -> prefetch registers
+        int img, ty0, tx0;
+        tile_org(t, img, ty0, tx0);
+        const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
+        if constexpr (CIK == 4) {
+            const rsrc_t rs = make_rsrc(P.x1 + (int64_t)img * P.hin * P.win * 3);
+#pragma unroll
+            for (int j = 0; j < DC_PF; ++j) {
+                const int i = tid + j * DC_THREADS;
+                const int iy = i / rowf, f = i - iy * rowf;
+                const int gy = iy0 + iy, gx3 = ix0 * 3 + f;
+                const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx3 < (unsigned)(P.win * 3);
+                pf1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.win * 3 + gx3) * 4) : OOB, 0, 0);
+            }
+        } else {
+            // one source: buffer loads, out-of-image lanes at the out-of-range marker.  Two sources ([decoder | ctx skip]): the
+            // descriptor would be lane-dependent (a waterfall loop per load), so plain loads through a selected pointer, halo
+            // lanes at the image's first pixel and zeroed when they land.
+            const float* s1 = P.x1 + (int64_t)img * P.hin * P.win * P.ld1;
+            if (!P.x2) {
+                const rsrc_t rs1 = make_rsrc(s1);
+#pragma unroll
+                for (int j = 0; j < DC_PF; ++j) {
+                    const int i = tid + j * DC_THREADS;
+                    const int pi = i / C4, c = (i - pi * C4) * 4;
+                    const int iy = pi / P.IW, ix = pi - iy * P.IW;
+                    const int gy = iy0 + iy, gx = ix0 + ix;
+                    const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
+                    pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? (uint32_t)(((gy * P.win + gx) * P.ld1 + c) * 4) : OOB, 0, 0);
+                }
+            } else {
+                const float* s2 = P.x2 + (int64_t)(img % P.nmod2) * P.hin * P.win * P.ld2;
+#pragma unroll
+                for (int j = 0; j < DC_PF; ++j) {
+                    const int i = tid + j * DC_THREADS;
+                    const int pi = i / C4, c = (i - pi * C4) * 4;
+                    const int iy = pi / P.IW, ix = pi - iy * P.IW;
+                    const int gy = iy0 + iy, gx = ix0 + ix;
+                    const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
+                    const int pix = ok ? gy * P.win + gx : 0;
+                    const float* p = c < P.c1 ? s1 + (int64_t)pix * P.ld1 + c : s2 + (int64_t)pix * P.ld2 + (c - P.c1);
+                    pf[j] = *reinterpret_cast<const dc_u32x4*>(p);
+                }
+            }
+        }
+    };
+    // (two-source tiles: whether slot j of tile t is a halo lane outside the image -- recomputed when it lands)
+    auto halo = [&](int t, int j) {
+        int img, ty0, tx0;
+        tile_org(t, img, ty0, tx0);
+        const int i = tid + j * DC_THREADS, pi = i / C4, iy = pi / P.IW, ix = pi - iy * P.IW;
+        const int gy = P.S * ty0 + P.y_org + iy, gx = P.S * tx0 + P.x_org + ix;
+        return !((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win);
+    };
+    auto land = [&](int t) {                                  // prefetch registers -> LDS tile
+        if constexpr (CIK == 4) {
+#pragma unroll
+            for (int j = 0; j < DC_PF; ++j) {
+                const int i = tid + j * DC_THREADS;
+                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
+                if (i < ntile_e) tile[(iy * P.IW + ix) * 4 + ch] = __uint_as_float(pf1[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DC_PF; ++j) {
+                const int i = tid + j * DC_THREADS;
+                const int pi = i / C4, c = (i - pi * C4) * 4;
+                if (i < ntile_e) *reinterpret_cast<dc_u32x4*>(&tile[pi * CIP + c]) = (P.x2 && halo(t, j)) ? dc_u32x4{0u, 0u, 0u, 0u} : pf[j];
+            }
+        }
+    };
 
     const int rbw = P.TW >> 4;                               // row blocks per tile row
     const int nrb = P.TH * rbw;                              // row blocks of the tile (<= DC_NW * MI)
@@ -150,93 +235,152 @@ __global__ __launch_bounds__(DC_THREADS, 2) void dconv_fwd_kernel(const DcFwd P,
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int rb = wv + DC_NW * mi, ty = rb / rbw, tx = (rb - ty * rbw) * 16 + l15;
-        abase[mi] = rb < nrb ? ((P.S * ty) * P.IW + P.S * tx) * CIP : 0;
+        abase[mi] = rb < nrb ? ((P.S * ty) * P.IW + P.S * tx) * CIP * 4 : 0;      // bytes
     }
     const bool active = wv < nrb;
-    if (P.wres) __syncthreads();                             // tile + filter visible
 
-    for (int ci = 0; ci < P.ncls; ++ci) {
-        DcClass cl;                                          // (static indices: a dynamic one would put the argument struct in scratch)
-        switch (ci) { case 0: cl = P.cls[0]; break; case 1: cl = P.cls[1]; break; case 2: cl = P.cls[2]; break; default: cl = P.cls[3]; break; }
-        f32x4 acc[MI][NB];
+    int ncol[NB], ncl[NB], nmk[NB];
+    float bias_v[NB];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+    for (int nb = 0; nb < NB; ++nb) {
+        ncol[nb] = P.n0 + nb * 16 + l15;
+        ncl[nb] = ncol[nb] < P.N ? ncol[nb] : 0;                                        // a column that exists, for loads whose value is then unused
+        nmk[nb] = ncol[nb] < P.N && ncol[nb] < P.ep.nsplit ? ncol[nb] : 0;
+        bias_v[nb] = (P.ep.bias && ncol[nb] < P.N) ? P.ep.bias[ncol[nb]] : 0.f;
+    }
+    int t = blockIdx.x;
+    if (t < ntiles) issue(t);
+    for (; t < ntiles; t += gridDim.x) {
+        __syncthreads();                                     // the previous tile's fragments are consumed (first pass: 4th channel zeroed)
+        land(t);
+        __syncthreads();                                     // tile (and, first pass, the filter) visible
+        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x);
+        int img, ty0, tx0;
+        tile_org(t, img, ty0, tx0);
+
+        for (int ci = 0; ci < P.ncls; ++ci) {
+            DcClass cl;                                      // (static indices: a dynamic one would put the argument struct in scratch)
+            switch (ci) { case 0: cl = P.cls[0]; break; case 1: cl = P.cls[1]; break; case 2: cl = P.cls[2]; break; default: cl = P.cls[3]; break; }
+            f32x4 acc[MI][NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int ntp_all = (cl.ntaps + TPC - 1) / TPC * TPC;
-        const int gts = P.wres ? ntp_all : P.GT;
-        for (int t0 = 0; t0 < ntp_all; t0 += gts) {
-            const int ntp = ntp_all - t0 < gts ? ntp_all - t0 : gts;
-            if (!P.wres) {
-                __syncthreads();                             // tile complete / the previous stage's fragments consumed
-                stage(cl.pslot0 + t0, ntp);
-                __syncthreads();
-            }
-            const int nchunks = active ? ntp / TPC * CPT : 0;
-            const int kW = P.wres ? (cl.pslot0 + t0) * CIK : 0;          // LDS-K coordinate of this stage's first slot
-            const int k0 = t0 * CIK + 4 * kg;                            // class-K coordinate of this lane's first k
-            float4 a4[2][MI], b4[2][NB];
-            auto fetch = [&](int c, int buf) {
-                const int k16 = k0 + 16 * c;
-                int e = k16 / CIK;
-                const int kin = k16 - e * CIK;
-                e = e < cl.ntaps ? e : cl.ntaps - 1;                     // padded slots: any valid address (their filter rows are zero)
-                const int q = (e * cl.mdiv) >> 8, r = e - q * cl.ntx;
-                const int to = ((cl.dy0 + cl.sgn * q) * P.IW + cl.dx0 + cl.sgn * r) * CIP + kin;
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a4[buf][mi] = *reinterpret_cast<const float4*>(&tile[abase[mi] + to]);
+                for (int nb = 0; nb < NB; ++nb) acc[mi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // chunks [g0, g1) of the packed filter = this class; per chunk a lane needs tab[g][kg] (byte offset of its tap / channel
+            // group inside the tile, built once per block) and filter rows 4 g + kg
+            const int g0 = cl.pslot0 * CIK / 16;
+            const int g1 = g0 + (cl.ntaps + TPC - 1) / TPC * CPT;
+            auto run = [&](auto nmi_c) {
+                constexpr int NMI = decltype(nmi_c)::value;  // row blocks this wave really has (MI, or MI - 1 in a tile whose last round of row blocks is partial)
+                float4 a4[2][NMI > 0 ? NMI : 1], b4[2][NB];
+                int tnext = tab[g0 * 4 + kg];
+                const char* bp = reinterpret_cast<const char*>(W4) + ((size_t)(4 * g0 + kg) * NP + l15) * 16;
+                auto fetch = [&](int buf) {
+                    const int to = tnext;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb)
-                    b4[buf][nb] = *reinterpret_cast<const float4*>(&W4[((kW / 4 + 4 * c + kg) * NP + nb * 16 + l15) * 4]);
+                    for (int mi = 0; mi < NMI; ++mi) a4[buf][mi] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tile) + abase[mi] + to);
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) b4[buf][nb] = *reinterpret_cast<const float4*>(bp + nb * 256);
+                    bp += 64 * NP;
+                };
+                auto mma = [&](int buf) {
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+                        for (int mi = 0; mi < NMI; ++mi) {
+                            const float av = tt == 0 ? a4[buf][mi].x : tt == 1 ? a4[buf][mi].y : tt == 2 ? a4[buf][mi].z : a4[buf][mi].w;
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) {
+                                const float bv = tt == 0 ? b4[buf][nb].x : tt == 1 ? b4[buf][nb].y : tt == 2 ? b4[buf][nb].z : b4[buf][nb].w;
+                                acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
+                            }
+                        }
+                    }
+                };
+                // software pipeline: fragments (and the table entry) of chunk g + 1 are read before the MFMAs of chunk g
+                fetch(0);
+                int g = g0;
+                for (; g + 2 < g1; g += 2) {
+                    tnext = tab[(g + 1) * 4 + kg];
+                    fetch(1);
+                    mma(0);
+                    tnext = tab[(g + 2) * 4 + kg];
+                    fetch(0);
+                    mma(1);
+                }
+                if (g + 1 < g1) { tnext = tab[(g + 1) * 4 + kg]; fetch(1); mma(0); mma(1); }
+                else mma(0);
             };
-            auto mma = [&](int buf) {
+            if (wv + DC_NW * (MI - 1) < nrb) run(std::integral_constant<int, MI>{});
+            else if constexpr (MI > 1) { if (active) run(std::integral_constant<int, MI - 1>{}); }
+            // ---- epilogue of this class.  D: col = l15, row = 4 * kg + r.  The terms an element needs from memory (skip-gradient
+            // adds, the saved activation behind lrelu') are loaded for a whole row block at once and only then applied: one
+            // latency per row block, not one per element (epi_store's load -> wait -> store chain took longer than the MFMA loop).
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
+            for (int mi = 0; mi < MI; ++mi) {
+                const int rb = wv + DC_NW * mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
+                const int y = ty0 + ty;
+                if (rb >= nrb || y >= P.hlog) continue;
+                int64_t pix[4];
+                bool okx[4];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const float av = tt == 0 ? a4[buf][mi].x : tt == 1 ? a4[buf][mi].y : tt == 2 ? a4[buf][mi].z : a4[buf][mi].w;
+                for (int r = 0; r < 4; ++r) {
+                    const int x = tx0 + txb + 4 * kg + r;
+                    okx[r] = x < P.wlog;
+                    pix[r] = ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * (okx[r] ? x : 0) + cl.ox);
+                }
+                float t1[4][NB], t2[4][NB], tm[4][NB];
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const float bv = tt == 0 ? b4[buf][nb].x : tt == 1 ? b4[buf][nb].y : tt == 2 ? b4[buf][nb].z : b4[buf][nb].w;
-                            acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) { t1[r][nb] = 0.f; t2[r][nb] = 0.f; tm[r][nb] = 1.f; }
+                if (P.ep.add1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t pa = (P.ep.add1_mod && pix[r] >= P.ep.add1_mod) ? pix[r] - P.ep.add1_mod : pix[r];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) t1[r][nb] = P.ep.add1[pa * P.ep.lda1 + ncl[nb]];      // (branch-free: clamped column, unused lanes are never stored)
+                    }
+                }
+                if (P.ep.add2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) t2[r][nb] = P.ep.add2[pix[r] * P.ep.lda2 + ncl[nb]];
+                }
+                if (P.ep.mask) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            tm[r][nb] = P.ep.mask[pix[r] * P.ep.ldm + nmk[nb]];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!okx[r]) continue;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int n = ncol[nb];
+                        if (n >= P.N) continue;
+                        float v = acc[mi][nb][r] + bias_v[nb] + t1[r][nb];
+                        v += t2[r][nb];
+                        if (P.ep.lrelu) v = fmaxf(v, (P.ep.lrelu == 2 ? 0.f : LEAK) * v);
+                        if (n < P.ep.nsplit) {
+                            if (P.ep.mask) v *= tm[r][nb] >= 0.f ? 1.f : LEAK;
+                            P.ep.out1[pix[r] * P.ep.ld1 + n] = v;
+                        } else {
+                            P.ep.out2[pix[r] * P.ep.ld2 + (n - P.ep.nsplit)] = v;
                         }
                     }
                 }
-            };
-            // software pipeline, branch-free in the steady state: fragments of chunk c + 1 are read before the MFMAs of chunk c
-            if (nchunks > 0) {
-                fetch(0, 0);
-                int c = 0;
-                for (; c + 2 < nchunks; c += 2) {
-                    fetch(c + 1, 1);
-                    mma(0);
-                    fetch(c + 2, 0);
-                    mma(1);
-                }
-                if (c + 1 < nchunks) { fetch(c + 1, 1); mma(0); mma(1); }
-                else mma(0);
             }
-        }
-        // ---- epilogue of this class.  D: col = l15, row = 4 * kg + r
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int rb = wv + DC_NW * mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
-            const int y = ty0 + ty;
-            if (rb >= nrb || y >= P.hlog) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int x = tx0 + txb + 4 * kg + r;
-                if (x >= P.wlog) continue;
-                const int64_t pix = ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * x + cl.ox);
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int n = nb * 16 + l15;
-                    if (n < P.N) epi_store(P.ep, 0, pix, n, acc[mi][nb][r]);
-                }
-            }
+            // Every class ends with all of the wave's memory operations retired.  Without this the compiler's wait-count
+            // bookkeeping cannot prove, across the loop back-edges, that the epilogue's loads into registers the next fragment
+            // reads reuse are complete, and it puts an s_waitcnt vmcnt(0) in front of the first ds_read of the MFMA loop --
+            // i.e. it waits for the NEXT tile's prefetch right after issuing it (seen in the ISA; the prefetch then hid nothing).
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
         }
     }
-    (void)ntiles;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -8,25 +8,30 @@
 namespace ctx {
 
 namespace {
-constexpr int LDS_BUDGET = 150 * 1024;      // of the 160 KiB per CU: one block of 8 waves
+constexpr int LDS_TOTAL = 160 * 1024;       // per CU
+constexpr int LDS_BUDGET = 156 * 1024;      // one block of 8 waves
+constexpr int NUM_CU = 256;
 
 int cik_of(int CI) { return CI == 3 ? 4 : CI <= 8 ? 8 : CI <= 16 ? 16 : CI <= 32 ? 32 : 64; }
 
+// instantiated (MI, NB): accumulators + double-buffered fragments + the 12 prefetch slots stay inside 256 registers
+// (4 x 2, 4 x 4, 3 x 4 and anything x 8 spill)
+bool fwd_cfg_ok(int mi, int nb) { return nb == 1 ? mi <= 4 : nb == 2 ? mi <= 3 : nb == 4 ? mi <= 2 : false; }
+
+template <int CIK, int MI, int NB>
+void launch_fwd_one(hipStream_t s, const DcFwd& P, dim3 grid, size_t lds, int ntiles, int nslots) {
+    if constexpr ((NB == 1 && MI <= 4) || (NB == 2 && MI <= 3) || (NB == 4 && MI <= 2)) {
+        static bool raised = false;
+        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; }
+        hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, NB>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);
+    }
+}
+
 template <int CIK, int MI>
 void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds, int ntiles, int nslots) {
-#define DC_CASE(nb)                                                                                                          \
-    case nb: {                                                                                                               \
-        static bool raised = false;                                                                                          \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET + 8192); raised = true; } \
-        hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, nb>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);                              \
-        break;                                                                                                               \
-    }
-    if constexpr (MI <= 2) {
-        switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
-    } else {
-        switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) default: break; }      // MI 3 / 4 with 8 column blocks would spill; never chosen
-    }
-#undef DC_CASE
+    if (NB == 4) launch_fwd_one<CIK, MI, 4>(s, P, grid, lds, ntiles, nslots);
+    else if (NB == 2) launch_fwd_one<CIK, MI, 2>(s, P, grid, lds, ntiles, nslots);
+    else launch_fwd_one<CIK, MI, 1>(s, P, grid, lds, ntiles, nslots);
 }
 
 template <int CIK>
@@ -47,90 +52,102 @@ bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 3
 
 // Fills tiles / LDS split and launches.  `span` = extent of the tap offsets (5 for the 5x5 taps over the input, 3 for a
 // stride-2 transposed conv over its small grid).
+//
+// Tile choice by a small time model of the persistent kernel (cycles per tile on one CU):
+//   compute = MFMAs of the busiest SIMD (row block rb sits on wave rb % 8, i.e. SIMD rb % 4) x 32
+//   load    = tile bytes / 16 B per clock  (in flight under the previous tile's MFMA loop: only max(compute, load) shows)
+//   land    = tile bytes / 79 B per clock  (ds_write_b128 of the prefetch registers), fixed = barriers + epilogue
+//   T = max(compute, load) + (land + fixed) / blocks per CU,   score = real output pixels per tile / T
+// subject to: tile + resident filter <= LDS, tile elements <= 512 x DC_PF prefetch slots.  A filter too big to stay
+// resident beside any tile is run as several launches over column slices of 16 * NB (d_h3's input gradient in
+// ContextAEReal: 25 x 32 x 32 floats = 100 KB -> two slices of 16 columns).
 static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     const int CIK = cik_of(P.CI), CIP = dc_cip(CIK);
-    int NB = (P.N + 15) / 16;
-    NB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
-    const int NP = NB * 16, TPC = CIK >= 16 ? 1 : 16 / CIK;
+    int NBT = (P.N + 15) / 16;
+    NBT = NBT <= 1 ? 1 : NBT <= 2 ? 2 : NBT <= 4 ? 4 : 8;
+    const int TPC = CIK >= 16 ? 1 : 16 / CIK, CPT = CIK >= 16 ? CIK / 16 : 1;
     // the filter in the LDS image's order: classes padded to whole 16-k chunks
-    int nslots = 0, maxt = 0;
+    int nslots = 0, nchunks = 0;
     for (int c = 0; c < P.ncls; ++c) {
         P.cls[c].pslot0 = nslots;
         const int ntp = (P.cls[c].ntaps + TPC - 1) / TPC * TPC;
         nslots += ntp;
-        maxt = ntp > maxt ? ntp : maxt;
+        nchunks += ntp / TPC * CPT;
     }
-    const size_t wall = (size_t)nslots * CIK * NP * 4 + (size_t)nslots * 4 + 64;
-    const size_t wmin = (size_t)4 * TPC * CIK * NP * 4 + 256;     // staged mode: at least four chunks of taps at a time
-    // tile: TW in {16, 32, 64} (<= the logical row), TH rows; MI = row blocks per wave.  Cost model: the matrix pipes are
-    // per SIMD and wave w sits on SIMD w % 4, so a tile takes the time of its busiest SIMD; scored as useful row blocks per
-    // (4 x busiest SIMD), times the share of real rows in ragged last tiles, times the halo overhead of the input tile,
-    // with a penalty when the filter cannot stay resident beside the tile (it is then re-staged per tile, with barriers).
-    int best_th = 1, best_mi = 1, best_tw = 16, best_res = 1;
+    int best_th = 0, best_mi = 1, best_tw = 16, best_nb = 1, best_occ = 1;
     double best = -1;
-    const int mi_max = NB >= 8 ? 2 : 4;                       // accumulators: MI * NB * 4 registers
-    for (int tw = 16; tw <= 64 && tw <= (P.wlog + 15) / 16 * 16; tw *= 2)
-        for (int mi = 1; mi <= mi_max; ++mi)
-            for (int th = 1; th <= 16; ++th) {
-                const int nrb = th * (tw / 16);
-                if (nrb > DC_NW * mi) break;
-                const int ih = P.S * (th - 1) + span, iw = P.S * (tw - 1) + span;
-                const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
-                const bool res = tile + wall <= (size_t)LDS_BUDGET;
-                if (!res && tile + wmin > (size_t)LDS_BUDGET) break;
-                int load[4] = {0, 0, 0, 0};
-                for (int rb = 0; rb < nrb; ++rb) load[rb & 3] += 1;                   // row block rb runs on wave rb % 8, i.e. SIMD rb % 4
-                int busiest = 1;
-                for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
-                const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
-                const double eff = (double)nrb / (4.0 * busiest) * ((double)P.hlog * P.wlog / ((double)tiles_y * th * tiles_x * tw)) *
-                                   ((double)(th * tw * P.S * P.S) / (ih * iw)) * (mi >= 2 ? 1.0 : 0.9) * (res ? 1.0 : 0.7) *
-                                   (nrb >= 8 ? 1.0 : 0.8) *                         // few active waves hide little latency
-                                   (2 * (tile + (res ? wall : wmin)) <= (size_t)LDS_BUDGET ? 1.0 : 0.85);  // two blocks per CU: one's loads under the other's MFMAs
-                if (eff > best) { best = eff; best_th = th; best_mi = mi; best_tw = tw; best_res = res; }
-            }
+    for (int nb = NBT > 4 ? 4 : NBT; nb >= 1; nb /= 2) {
+        const size_t wall = (size_t)nslots * CIK * nb * 16 * 4 + (size_t)(nslots * CIK / 16 + 1) * 16;
+        for (int tw = 16; tw <= 64 && tw <= (P.wlog + 15) / 16 * 16; tw *= 2)
+            for (int mi = 1; mi <= 4 && fwd_cfg_ok(mi, nb); ++mi)
+                for (int th = 1; th <= 32; ++th) {
+                    const int nrb = th * (tw / 16);
+                    if (nrb > DC_NW * mi) break;
+                    if (mi > 1 && nrb <= DC_NW * (mi - 1)) continue;      // a smaller MI covers this tile
+                    const int ih = P.S * (th - 1) + span, iw = P.S * (tw - 1) + span;
+                    const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4;
+                    if (tile + wall > (size_t)LDS_BUDGET) break;
+                    if ((int64_t)ih * iw * (CIK == 4 ? 3 : CIK / 4) > (int64_t)DC_THREADS * DC_PF) break;
+                    int load[4] = {0, 0, 0, 0};
+                    for (int rb = 0; rb < nrb; ++rb) load[rb & 3] += 1;
+                    int busiest = 1;
+                    for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
+                    const int occ = 1;       // (the kernels take 110-250 registers: one block of 8 waves per CU)
+                    const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
+                    const double rows = (double)P.hlog * P.wlog / ((double)tiles_y * tiles_x);          // real output pixels per tile
+                    const double compute = (double)busiest * nb * 4.0 * nchunks * 32.0;
+                    const double loadc = (double)tile / 16.0, land = (double)tile / 79.0, fixed = 700.0 + 40.0 * mi * nb * P.ncls;
+                    const double T = (compute > loadc ? compute : loadc) + (land + fixed) / occ;
+                    const double score = rows / (T * (NBT / nb));
+                    if (score > best) { best = score; best_th = th; best_mi = mi; best_tw = tw; best_nb = nb; best_occ = occ; }
+                }
+    }
+    if (!best_th) { fprintf(stderr, "dconv: no tile fits (CI %d N %d)\n", P.CI, P.N); return; }
     if (g_dc_force[0]) {
         best_th = g_dc_force[0]; best_tw = g_dc_force[1]; best_mi = g_dc_force[2];
         const int ih = P.S * (best_th - 1) + span, iw = P.S * (best_tw - 1) + span;
-        best_res = (size_t)((ih * iw * CIP + 3) & ~3) * 4 + wall <= (size_t)LDS_BUDGET;
+        const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4, wall = (size_t)nslots * CIK * best_nb * 16 * 4 + (size_t)(nslots * CIK / 16 + 1) * 16;
+        g_dc_last[0] = 0;
+        if (tile + wall > (size_t)LDS_BUDGET || (int64_t)ih * iw * (CIK == 4 ? 3 : CIK / 4) > (int64_t)DC_THREADS * DC_PF) return;
+        best_occ = 1;
+        if (!fwd_cfg_ok(best_mi, best_nb)) return;
     }
     P.TW = best_tw;
     P.TH = best_th;
-    const int MI = best_mi;
+    const int MI = best_mi, NB = best_nb;
     P.IH = P.S * (P.TH - 1) + span;
     P.IW = P.S * (P.TW - 1) + span;
     P.tiles_y = (P.hlog + P.TH - 1) / P.TH;
     P.tiles_x = (P.wlog + P.TW - 1) / P.TW;
+    P.NPT = NBT * 16;
     const size_t tile = (size_t)((P.IH * P.IW * CIP + 3) & ~3) * 4;
-    P.wres = best_res;
-    int gt = nslots;
-    if (!P.wres) {
-        gt = (int)(((size_t)LDS_BUDGET - tile - 256) / ((size_t)CIK * NP * 4)) / TPC * TPC;
-        if (gt > maxt) gt = maxt;
-        if (gt < TPC) gt = TPC;
-    }
-    P.GT = gt;
-    g_dc_last[0] = P.TH; g_dc_last[1] = P.TW; g_dc_last[2] = MI; g_dc_last[3] = P.wres ? -nslots : gt;
-    const size_t lds = tile + (size_t)(P.wres ? nslots : gt) * CIK * NP * 4 + (size_t)(nslots + 4) * 4;
+    g_dc_last[0] = P.TH; g_dc_last[1] = P.TW; g_dc_last[2] = MI; g_dc_last[3] = NB * 10 + best_occ;
+    const size_t lds = tile + (size_t)nslots * CIK * NB * 16 * 4 + (size_t)(nslots * CIK / 16 + 1) * 16;      // tile | filter | offset table
     const int ntiles = P.nimg * P.tiles_y * P.tiles_x;
-    const dim3 grid((unsigned)ntiles);
+    // persistent grid: whole rounds over the CUs' block slots
+    const int slots = NUM_CU * best_occ;
+    const int rounds = (ntiles + slots - 1) / slots;
+    const dim3 grid((unsigned)((ntiles + rounds - 1) / rounds));
     {
-        const int total = nslots * CIK * NP;
+        const int total = nslots * CIK * P.NPT;
         const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
         switch (CIK) {
-            case 4: hipLaunchKernelGGL((dconv_pack_kernel<4>), pg, dim3(256), 0, s, P, NP, nslots); break;
-            case 8: hipLaunchKernelGGL((dconv_pack_kernel<8>), pg, dim3(256), 0, s, P, NP, nslots); break;
-            case 16: hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, NP, nslots); break;
-            case 32: hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, NP, nslots); break;
-            default: hipLaunchKernelGGL((dconv_pack_kernel<64>), pg, dim3(256), 0, s, P, NP, nslots); break;
+            case 4: hipLaunchKernelGGL((dconv_pack_kernel<4>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+            case 8: hipLaunchKernelGGL((dconv_pack_kernel<8>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+            case 16: hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+            case 32: hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+            default: hipLaunchKernelGGL((dconv_pack_kernel<64>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
         }
     }
-    switch (CIK) {
-        case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-        case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-        case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-        case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-        default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+    for (int n0 = 0; n0 < P.N; n0 += NB * 16) {
+        P.n0 = n0;
+        switch (CIK) {
+            case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+            case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+            case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+            case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+            default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+        }
     }
 }
 
@@ -192,7 +209,7 @@ void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds
 #define DC_CASE(nb)                                                                                                          \
     case nb: {                                                                                                               \
         static bool raised = false;                                                                                          \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET + 8192); raised = true; } \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; } \
         hipLaunchKernelGGL((dconv_wgrad_kernel<CAK, RBW, nb>), grid, dim3(DC_THREADS), lds, s, P);                           \
         break;                                                                                                               \
     }

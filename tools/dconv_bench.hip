@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
         dconv_force_tile(0, 0, 0);
         if (only >= 0) { run(); run(); run(); (void)hipStreamSynchronize(st); return 0; }
         const float t_auto = timeit();
-        printf("%s  auto: TH %d TW %d MI %d GT %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
+        printf("%s  auto: TH %d TW %d MI %d NB*10+occ %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
                flops / t_auto / 1e9);
         struct R { int th, tw, mi; float ms; };
         std::vector<R> rs;
@@ -100,11 +100,9 @@ int main(int argc, char** argv) {
                     const int span = L.kind == 2 ? 3 : 5, S = L.kind == 0 ? L.S : 1;
                     const int cik = L.CI == 3 ? 4 : L.CI, cip = cik == 4 ? 4 : cik + 4;
                     const size_t tile = (size_t)(S * (th - 1) + span) * (S * (tw - 1) + span) * cip * 4;
-                    if (tile + 20000 > 150 * 1024) continue;
-                    if (mi > 2 && L.N > 64) continue;
                     dconv_force_tile(th, tw, mi);
                     const float ms = timeit();
-                    if (ms > 0) rs.push_back({th, tw, mi, ms});
+                    if (ms > 0 && g_dc_last[0] == th && g_dc_last[1] == tw && g_dc_last[2] == mi) rs.push_back({th, tw, mi, ms});
                 }
         }
         for (int k = 0; k < 6 && !rs.empty(); ++k) {
