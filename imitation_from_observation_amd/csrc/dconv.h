@@ -52,7 +52,7 @@ struct DcFwd {
     int y_org, x_org;                              // input pixel of logical output (0,0) at tap offset (0,0)
     int hlog, wlog;                                // logical output grid = the GEMM's row space (transposed stride 2: the small grid)
     int TH, TW;                                    // tile of logical outputs: TH * TW / 16 row blocks <= DC_NW * MI
-    int IH, IW;                                    // input tile incl. halo
+    int IH, IW, CIP;                               // input tile incl. halo; its pixel stride in LDS (dc_cip)
     const float* w; int wmode;                     // 0: w[tap][k][n]   1: w[tap][n][k]
     int n0, NPT;                                   // this launch computes output columns [n0, n0 + 16 * NB) (filters too big to sit in LDS beside
                                                    // a tile are run as several column slices); NPT = column count of the packed image
@@ -66,7 +66,10 @@ struct DcFwd {
     Epi ep;
 };
 
-__host__ __device__ inline int dc_cip(int cik) { return cik + 4 - (cik == 4 ? 4 : 0); }      // LDS pixel stride: CIK + 4 (bank spread), 4 for the 3-channel tile
+// LDS pixel stride of the input tile.  A fragment read is a ds_read_b128 at (S * CIP) * l15 + 4 * kg dwords; its four 16-lane
+// groups are conflict-free exactly when S * CIP = 8 mod 16 (or 4 / 8 outright) -- enumerated over the hardware's lane groups;
+// CIK + 4 for every stride cost 2x on the stride-1 layers (SQ_LDS_BANK_CONFLICT = a third of the LDS cycles).
+__host__ __device__ inline int dc_cip(int cik, int S) { return cik == 4 ? 4 : cik == 8 ? (S == 1 ? 8 : 12) : cik + (S == 1 ? 8 : 4); }
 
 // wp[slot][k / 4][n][k & 3] for every class-padded tap slot (zeros in the padding: slots past a class's taps, k >= CI, n >= N)
 template <int CIK>
@@ -103,7 +106,7 @@ typedef unsigned dc_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int CIK, int MI, int NB>
 __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
-    constexpr int CIP = CIK == 4 ? 4 : CIK + 4;
+    const int CIP = P.CIP;                                 // (only in address set-up: the MFMA loop reads through abase[] + tab[])
     constexpr int NP = NB * 16;
     constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;          // taps per 16-k chunk
     constexpr int CPT = CIK >= 16 ? CIK / 16 : 1;          // chunks per tap
@@ -386,147 +389,242 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
 // ------------------------------------------------------------------------------------------------
 // Filter gradient.  dw[tap][a][b] = sum over images and small-grid pixels p of big[S*p + tap - pad][a] * small[p][b].
 // GEMM rows m = tap * CA + a (M = 25 * CA, dense), columns b, K = pixels.  A block stages the small tile and the big halo
-// tile of one (image, tile) in LDS, runs all its row blocks over the tile's pixels, moves to its next tile (persistent,
-// accumulators stay in registers) and finally writes ONE partial [M][CB] to its slab; dconv_wgrad_reduce adds the slabs.
+// tile of one (image, tile) in LDS, runs its row blocks over the tile's pixels, moves to its next tile (persistent,
+// accumulators stay in registers) and finally writes ONE partial [M][NP] to its slab; dconv_wgrad_reduce adds the slabs.
+// The 8 waves are WM groups along M x WK groups along K: a 3-channel `big` has only 5 row blocks (M = 75), so every wave
+// takes all of them for an eighth of the tile's pixels (WM 1 x WK 8, B fragments shared by five row blocks) and the eight
+// partials are added in a fixed tree through LDS when the block retires; 32 channels are 50 row blocks = 8 waves x 7.
+// Like the forward kernel, the next tile's global loads are in flight (registers) under the current tile's MFMA loop.
 // ------------------------------------------------------------------------------------------------
 struct DcWgrad {
     const float* big; int ldb; int CA;              // big-grid tensor (channels a); CA == 3: read as [pixel][3]
     const float* s1; int ld1; int c1;              // small-grid tensor, channels [0, c1)
     const float* s2; int ld2; int nmod2;           // channels [c1, CB) from tensor 2 (ctx skip, image % nmod2)
     int CB;                                        // c1 + c2, a multiple of 8
+    int n0;                                        // this launch: columns [n0, n0 + 16 * NB) of CB
     int hb, wb, hs, ws, nimg;
     int S, pad;
     int TH, TW, tw_sh;                             // small-grid tile, TW = 1 << tw_sh in {16, 32, 64}, so TH*TW is a multiple of 16
     int IH, IW;                                    // big tile incl. halo: S*(TH-1)+5, S*(TW-1)+5
     int tiles_y, tiles_x, ntiles;                  // per image; ntiles = nimg * tiles_y * tiles_x
     int M;                                         // 25 * CA
-    int RBW;                                       // row blocks (of 16 rows of M) per wave
-    float* slab;                                   // [gridDim.x][M][CBP]
+    float* slab;                                   // [gridDim.x][M][NP]
     float* out;                                    // dw [25][CA][CB]
 };
 
-template <int CAK /* big-tile pixel stride class: 4 (CA = 3), 8, 16, 32 */, int RBW, int NB>
+constexpr int DC_PFB = 14;                         // prefetch slots per thread, big tile (float4s; floats of a [pixel][3] tensor)
+__host__ __device__ constexpr int dc_cbp(int np, int S) { return np + (S == 2 ? 8 : 4); }   // small-tile pixel stride in LDS
+__host__ __device__ constexpr int dc_pfs(int nb) { return nb >= 4 ? 8 : 2 * nb; }   // small tile: TH*TW*NP/4 float4s <= 512 * this
+
+template <int CAK /* big-tile pixel stride class: 4 (CA = 3), 8, 16, 32 */, int RBW, int WM, int NB, int SS /* stride */>
 __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P) {
-    constexpr int CAP = CAK == 4 ? 4 : CAK + 4;             // pixel strides = 4 mod 16 dwords: the four pixel groups (kg) of a wave read
-    constexpr int NP = NB * 16;                             // 16-bank windows that do not overlap (4 pixels * stride = 16 mod 64)
-    constexpr int CBP = NP + 4;
+    // ds_read_b32 is served 32 lanes (two pixel groups kg) at a time over 32 banks, 16 consecutive dwords per group: the two
+    // groups must sit 16 banks apart.  Lane group kg takes pixels p0 = c + PD * kg + {0..3 | 0, 1, 8, 9}: PD = 4 pixels apart at
+    // stride 1 (4 * CAP = 16 mod 32 with CAP = CAK + 4; small tile 4 * (NP + 4)), PD = 2 at stride 2 (2 * 2 * CAP = 16 mod 32;
+    // small tile 2 * (NP + 8)) -- with PD = 4 at stride 2 both groups hit the same banks (measured: 43 % of the LDS cycles).
+    constexpr int CAP = CAK == 4 ? 4 : CAK + 4;
+    constexpr int NP = NB * 16;
+    constexpr int CBP = dc_cbp(NP, SS);
+    constexpr int PD = SS == 2 ? 2 : 4;
+    constexpr int WK = DC_NW / WM;
+    constexpr int C4 = CAK / 4, S4 = NP / 4, PFS = dc_pfs(NB);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+    const int wm = wv % WM, wk = wv / WM;
     float* bigt = smem;                                      // [IH*IW][CAP]
     float* smallt = smem + ((P.IH * P.IW * CAP + 3) & ~3);   // [TH*TW][CBP]
     const int npix = P.TH * P.TW;
 
-    // this lane's A rows: m = (wv * RBW + rb) * 16 + l15 -> (tap, a) -> offset of the tap inside the big tile + channel
+    // this lane's A rows: m = (wm * RBW + rb) * 16 + l15 -> (tap, a) -> byte offset of the tap inside the big tile + channel
     int aoff[RBW];
-    bool aok[RBW];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb) {
-        const int m = (wv * RBW + rb) * 16 + l15;
-        aok[rb] = m < P.M;
-        const int mm = aok[rb] ? m : 0;
+        const int m = (wm * RBW + rb) * 16 + l15;
+        const int mm = m < P.M ? m : 0;
         const int tap = mm / P.CA, a = mm - tap * P.CA, ky = tap / 5, kx = tap - 5 * ky;
-        aoff[rb] = (ky * P.IW + kx) * CAP + a;
+        aoff[rb] = ((ky * P.IW + kx) * CAP + a) * 4;
     }
     f32x4 acc[RBW][NB];
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (CAK == 4) for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) bigt[i * 4 + 3] = 0.f;   // never loaded, never read as data (a < 3)
 
-    for (int t = blockIdx.x; t < P.ntiles; t += gridDim.x) {
-        int b = t;
-        const int txi = b % P.tiles_x; b /= P.tiles_x;
-        const int tyi = b % P.tiles_y;
-        const int img = b / P.tiles_y;
-        const int ty0 = tyi * P.TH, tx0 = txi * P.TW;
-        const int iy0 = P.S * ty0 - P.pad, ix0 = P.S * tx0 - P.pad;
-        __syncthreads();                                     // previous tile consumed
-        // ---- big halo tile
+    const int nbig_e = CAK == 4 ? P.IH * P.IW * 3 : P.IH * P.IW * C4;
+    const int nsm_e = npix * S4;
+    const int rowf = P.IW * 3;
+    dc_u32x4 pb[CAK == 4 ? 1 : DC_PFB];
+    unsigned pb1[CAK == 4 ? DC_PFB : 1];
+    dc_u32x4 ps[PFS];
+    auto tile_org = [&](int t, int& img, int& ty0, int& tx0) {
+        const int txi = t % P.tiles_x; t /= P.tiles_x;
+        const int tyi = t % P.tiles_y;
+        img = t / P.tiles_y; ty0 = tyi * P.TH; tx0 = txi * P.TW;
+    };
+    auto issue = [&](int t) {
+        int img, ty0, tx0;
+        tile_org(t, img, ty0, tx0);
+        const int iy0 = SS * ty0 - P.pad, ix0 = SS * tx0 - P.pad;
         if constexpr (CAK == 4) {
-            const float* src = P.big + (int64_t)img * P.hb * P.wb * 3;
-            const int rowf = P.IW * 3;
-            for (int i = tid; i < P.IH * rowf; i += DC_THREADS) {
-                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                float v = 0.f;
-                if ((unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb) v = src[((int64_t)gy * P.wb + gx) * 3 + ch];
-                bigt[(iy * P.IW + ix) * 4 + ch] = v;
+            const rsrc_t rs = make_rsrc(P.big + (int64_t)img * P.hb * P.wb * 3);
+#pragma unroll
+            for (int j = 0; j < DC_PFB; ++j) {
+                const int i = tid + j * DC_THREADS;
+                const int iy = i / rowf, f = i - iy * rowf;
+                const int gy = iy0 + iy, gx3 = ix0 * 3 + f;
+                const bool ok = i < nbig_e && (unsigned)gy < (unsigned)P.hb && (unsigned)gx3 < (unsigned)(P.wb * 3);
+                pb1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.wb * 3 + gx3) * 4) : OOB, 0, 0);
             }
         } else {
-            constexpr int C4 = CAK / 4;
-            const float* src = P.big + (int64_t)img * P.hb * P.wb * P.ldb;
-            for (int i = tid; i < P.IH * P.IW * C4; i += DC_THREADS) {
+            const rsrc_t rs = make_rsrc(P.big + (int64_t)img * P.hb * P.wb * P.ldb);
+#pragma unroll
+            for (int j = 0; j < DC_PFB; ++j) {
+                const int i = tid + j * DC_THREADS;
                 const int pi = i / C4, c = (i - pi * C4) * 4;
                 const int iy = pi / P.IW, ix = pi - iy * P.IW;
                 const int gy = iy0 + iy, gx = ix0 + ix;
-                float4 v = zero4();
-                if (c < P.CA && (unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb) v = ldg4(src + ((int64_t)gy * P.wb + gx) * P.ldb + c);
-                *reinterpret_cast<float4*>(&bigt[pi * CAP + c]) = v;
+                const bool ok = i < nbig_e && c < P.CA && (unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb;
+                pb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(((gy * P.wb + gx) * P.ldb + c) * 4) : OOB, 0, 0);
             }
         }
-        // ---- small tile (zero outside the grid: those pixels contribute nothing)
-        {
-            const int C4 = NP / 4;
-            const float* p1 = P.s1 + (int64_t)img * P.hs * P.ws * P.ld1;
-            const float* p2 = P.s2 ? P.s2 + (int64_t)(img % P.nmod2) * P.hs * P.ws * P.ld2 : nullptr;
-            for (int i = tid; i < npix * C4; i += DC_THREADS) {
+        // small tile: zero outside the grid and past CB (those pixels / columns contribute nothing).  Two sources -> plain
+        // loads through a selected pointer (a lane-dependent buffer descriptor would cost a waterfall loop per load).
+        const float* p1 = P.s1 + (int64_t)img * P.hs * P.ws * P.ld1;
+        const float* p2 = P.s2 ? P.s2 + (int64_t)(img % P.nmod2) * P.hs * P.ws * P.ld2 : p1;
+#pragma unroll
+        for (int j = 0; j < PFS; ++j) {
+            const int i = tid + j * DC_THREADS;
+            const int pi = i / S4, c = P.n0 + (i - pi * S4) * 4;
+            const int ty = pi >> P.tw_sh, tx = pi - (ty << P.tw_sh);
+            const int gy = ty0 + ty, gx = tx0 + tx;
+            const bool ok = i < nsm_e && c < P.CB && gy < P.hs && gx < P.ws;
+            const int pix = ok ? gy * P.ws + gx : 0;
+            const int cc = ok ? c : 0;
+            const float* p = cc < P.c1 ? p1 + (int64_t)pix * P.ld1 + cc : p2 + (int64_t)pix * P.ld2 + (cc - P.c1);
+            ps[j] = *reinterpret_cast<const dc_u32x4*>(p);
+        }
+    };
+    auto land = [&](int t) {
+        int img, ty0, tx0;
+        tile_org(t, img, ty0, tx0);
+        if constexpr (CAK == 4) {
+#pragma unroll
+            for (int j = 0; j < DC_PFB; ++j) {
+                const int i = tid + j * DC_THREADS;
+                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
+                if (i < nbig_e) bigt[(iy * P.IW + ix) * 4 + ch] = __uint_as_float(pb1[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < DC_PFB; ++j) {
+                const int i = tid + j * DC_THREADS;
                 const int pi = i / C4, c = (i - pi * C4) * 4;
-                const int ty = pi / P.TW, tx = pi - ty * P.TW;
-                const int gy = ty0 + ty, gx = tx0 + tx;
-                float4 v = zero4();
-                if (c < P.CB && gy < P.hs && gx < P.ws) {
-                    const int64_t pix = (int64_t)gy * P.ws + gx;
-                    v = c < P.c1 ? ldg4(p1 + pix * P.ld1 + c) : ldg4(p2 + pix * P.ld2 + (c - P.c1));
-                }
-                *reinterpret_cast<float4*>(&smallt[pi * CBP + c]) = v;
+                if (i < nbig_e) *reinterpret_cast<dc_u32x4*>(&bigt[pi * CAP + c]) = pb[j];
             }
         }
+#pragma unroll
+        for (int j = 0; j < PFS; ++j) {
+            const int i = tid + j * DC_THREADS;
+            const int pi = i / S4, cl = (i - pi * S4) * 4;
+            const int ty = pi >> P.tw_sh, tx = pi - (ty << P.tw_sh);
+            const bool ok = P.n0 + cl < P.CB && ty0 + ty < P.hs && tx0 + tx < P.ws;
+            if (i < nsm_e) *reinterpret_cast<dc_u32x4*>(&smallt[pi * CBP + cl]) = ok ? ps[j] : dc_u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < P.ntiles) issue(t);
+    for (; t < P.ntiles; t += gridDim.x) {
+        __syncthreads();                                     // previous tile consumed
+        land(t);
         __syncthreads();
-        // ---- K loop over the tile's pixels, 16 per chunk: lane kg takes pixels 16c + 4kg + t.  Software-pipelined: the LDS
-        // reads of chunk c + 1 are issued before the MFMAs of chunk c.
-        float av[2][RBW][4], bv[2][NB][4];
-        auto fetch = [&](int c, int buf) {
-            const int p0 = c + 4 * kg;
+        if (t + (int)gridDim.x < P.ntiles) issue(t + gridDim.x);
+        // ---- K loop over this wave's share of the tile's pixels, 16 per chunk: lane group kg takes pixels c + 4 kg + tt.
+        // Software-pipelined: the LDS reads of the wave's next chunk are issued before the MFMAs of the current one.
+        // A lane's four pixels p0 .. p0 + 3 (p0 a multiple of 4, TW >= 16) sit in one tile row: one address per operand row,
+        // the pixels at compile-time offsets (ds_read with an immediate) -- not an address computation per value.
+        // Pipelined per k-step: the fragment registers of step tt are re-loaded for the wave's NEXT chunk right after the
+        // MFMAs of step tt have been issued (single-buffered: 4 * (RBW + NB) registers instead of twice that).
+        float av[RBW][4], bv[NB][4];
+        constexpr int CS = 16 * WK;                          // chunk stride of one wave
+        {
+            const char* pa[RBW];
+            const float* psm;
+            auto pofs = [](int tt) { return SS == 2 ? (tt & 1) + 8 * (tt >> 1) : tt; };      // pixel of k-step tt relative to p0 (same tile row: TW >= 16)
+            auto point = [&](int c) {
+                const int p0 = c + PD * kg, ty = p0 >> P.tw_sh, tx = p0 - (ty << P.tw_sh);
+                const char* pbig = reinterpret_cast<const char*>(bigt) + ((SS * ty) * P.IW + SS * tx) * (CAP * 4);
+                psm = smallt + p0 * CBP + l15;
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
-                const int p = p0 + tt, ty = p >> P.tw_sh, tx = p - (ty << P.tw_sh);
-                const int pbig = ((P.S * ty) * P.IW + P.S * tx) * CAP, psm = p * CBP;
+                for (int rb = 0; rb < RBW; ++rb) pa[rb] = pbig + aoff[rb];
+            };
+            auto fetch_tt = [&](int tt) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) bv[buf][nb][tt] = smallt[psm + nb * 16 + l15];
+                for (int nb = 0; nb < NB; ++nb) bv[nb][tt] = psm[pofs(tt) * CBP + nb * 16];
 #pragma unroll
-                for (int rb = 0; rb < RBW; ++rb) av[buf][rb][tt] = bigt[pbig + aoff[rb]];
-            }
-        };
-        auto mma = [&](int buf) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+                for (int rb = 0; rb < RBW; ++rb) av[rb][tt] = *reinterpret_cast<const float*>(pa[rb] + pofs(tt) * SS * CAP * 4);
+            };
+            auto mma_tt = [&](int tt) {
 #pragma unroll
                 for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][rb][tt], bv[buf][nb][tt], acc[rb][nb], 0, 0, 0);
-        };
-        fetch(0, 0);
-        for (int c = 0; c < npix; c += 32) {
-            if (c + 16 < npix) fetch(c + 16, 1);
-            mma(0);
-            if (c + 16 < npix) {
-                if (c + 32 < npix) fetch(c + 32, 0);
-                mma(1);
+                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rb][tt], bv[nb][tt], acc[rb][nb], 0, 0, 0);
+            };
+            int c = 16 * wk;
+            if (c < npix) {
+            point(c);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) fetch_tt(tt);
+            for (; c + CS < npix; c += CS) {
+                point(c + CS);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) { mma_tt(tt); fetch_tt(tt); }
+            }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) mma_tt(tt);
+            }
+        }
+    }
+    // ---- the WK partial sums of a row block -> one, in a fixed tree through LDS (deterministic)
+    if constexpr (WK > 1) {
+        float* red = smem;                                   // [WK / 2][WM][RBW][NB][4][64]
+#pragma unroll
+        for (int half = WK / 2; half >= 1; half /= 2) {
+            __syncthreads();                                 // tiles dead / previous round read
+            if (wk >= half && wk < 2 * half) {
+#pragma unroll
+                for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) red[(((((wk - half) * WM + wm) * RBW + rb) * NB + nb) * 4 + r) * 64 + lane] = acc[rb][nb][r];
+            }
+            __syncthreads();
+            if (wk < half) {
+#pragma unroll
+                for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[rb][nb][r] += red[((((wk * WM + wm) * RBW + rb) * NB + nb) * 4 + r) * 64 + lane];
             }
         }
     }
     // ---- partial -> slab[block][m][n]
-    float* sl = P.slab + (int64_t)blockIdx.x * P.M * NP;
+    if (wk == 0) {
+        float* sl = P.slab + (int64_t)blockIdx.x * P.M * NP;
 #pragma unroll
-    for (int rb = 0; rb < RBW; ++rb)
+        for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = (wv * RBW + rb) * 16 + 4 * kg + r;
-            if (m >= P.M) continue;
+            for (int r = 0; r < 4; ++r) {
+                const int m = ((wm * RBW) + rb) * 16 + 4 * kg + r;
+                if (m >= P.M) continue;
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) sl[(int64_t)m * NP + nb * 16 + l15] = acc[rb][nb][r];
-        }
+                for (int nb = 0; nb < NB; ++nb) sl[(int64_t)m * NP + nb * 16 + l15] = acc[rb][nb][r];
+            }
+    }
 }
 
 }  // namespace ctx

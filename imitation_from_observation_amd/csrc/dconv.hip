@@ -62,7 +62,8 @@ bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 3
 // resident beside any tile is run as several launches over column slices of 16 * NB (d_h3's input gradient in
 // ContextAEReal: 25 x 32 x 32 floats = 100 KB -> two slices of 16 columns).
 static void dconv_launch(hipStream_t s, DcFwd P, int span) {
-    const int CIK = cik_of(P.CI), CIP = dc_cip(CIK);
+    const int CIK = cik_of(P.CI), CIP = dc_cip(CIK, P.S);
+    P.CIP = CIP;
     int NBT = (P.N + 15) / 16;
     NBT = NBT <= 1 ? 1 : NBT <= 2 ? 2 : NBT <= 4 ? 4 : 8;
     const int TPC = CIK >= 16 ? 1 : 16 / CIK, CPT = CIK >= 16 ? CIK / 16 : 1;
@@ -191,29 +192,54 @@ void dconv_convt2(hipStream_t s, DcFwd P) {
 }
 
 // ---- filter gradient ------------------------------------------------------------------------------------------
-// out[m][n] = sum over slabs in fixed order
-__global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int M, int NP, int CB, float* __restrict__ out) {
-    const int64_t total = (int64_t)M * CB;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int m = (int)(i / CB), n = (int)(i - (int64_t)m * CB);
-        const float* p = slab + (int64_t)m * NP + n;
-        float v = 0.f;
-        for (int s = 0; s < nslab; ++s) v += p[(int64_t)s * M * NP];
-        out[i] = v;
+// out[m][n0 + n] = sum over the blocks' slabs, in a fixed order.  A block of 16 x 16 threads covers 16 float4s of the [M][NP]
+// image; thread (e, g) adds slabs g, g + 16, ... (independent loads, in flight together), then the 16 partials of an element
+// are added in order through LDS.  (One thread walking all 256 slabs of its element took 60 us per filter gradient -- more
+// than the gradient kernel of the small layers.)
+__global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float4* __restrict__ slab, int nslab, int M, int NP, int ncols, int n0, int CB, float* __restrict__ out) {
+    __shared__ float4 part[16][16];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int E4 = M * NP / 4, q = blockIdx.x * 16 + e;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < E4) {
+        const float4* p = slab + q;
+        for (int s0 = g; s0 < nslab; s0 += 64) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = s0 + 16 * u < nslab ? p[(int64_t)(s0 + 16 * u) * E4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+        }
+    }
+    part[g][e] = v;
+    __syncthreads();
+    if (g == 0 && q < E4) {
+        float4 r = part[0][e];
+        for (int k = 1; k < 16; ++k) { r.x += part[k][e].x; r.y += part[k][e].y; r.z += part[k][e].z; r.w += part[k][e].w; }
+        const int m = q / (NP / 4), n = (q - m * (NP / 4)) * 4;
+        float* o = out + (int64_t)m * CB + n0 + n;
+        if (n + 0 < ncols) o[0] = r.x;
+        if (n + 1 < ncols) o[1] = r.y;
+        if (n + 2 < ncols) o[2] = r.z;
+        if (n + 3 < ncols) o[3] = r.w;
     }
 }
 
 namespace {
-template <int CAK, int RBW>
+template <int CAK, int RBW, int WM, int SS>
 void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds) {
 #define DC_CASE(nb)                                                                                                          \
     case nb: {                                                                                                               \
         static bool raised = false;                                                                                          \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, nb>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; } \
-        hipLaunchKernelGGL((dconv_wgrad_kernel<CAK, RBW, nb>), grid, dim3(DC_THREADS), lds, s, P);                           \
+        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, WM, nb, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; } \
+        hipLaunchKernelGGL((dconv_wgrad_kernel<CAK, RBW, WM, nb, SS>), grid, dim3(DC_THREADS), lds, s, P);                       \
         break;                                                                                                               \
     }
-    switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) DC_CASE(8) default: break; }
+    if constexpr (CAK == 4) {
+        switch (NB) { DC_CASE(1) DC_CASE(2) DC_CASE(4) default: break; }
+    } else {
+        switch (NB) { DC_CASE(1) DC_CASE(2) default: break; }
+    }
 #undef DC_CASE
 }
 }  // namespace
@@ -222,24 +248,29 @@ void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
     const int CAK = P.CA == 3 ? 4 : P.CA <= 8 ? 8 : P.CA <= 16 ? 16 : 32;
     const int CAP = CAK == 4 ? 4 : CAK + 4;
-    int NB = (P.CB + 15) / 16;
-    NB = NB <= 1 ? 1 : NB <= 2 ? 2 : NB <= 4 ? 4 : 8;
-    const int NP = NB * 16, CBP = NP + 4;
+    // waves: WM groups along M x WK along K (the instantiations below); RBW row blocks of 16 per wave
+    const int RBW = CAK == 4 ? 5 : 7, WM = CAK == 4 ? 1 : CAK == 8 ? 2 : CAK == 16 ? 4 : 8, WK = DC_NW / WM;
+    int NBT = (P.CB + 15) / 16;
+    NBT = NBT <= 1 ? 1 : NBT <= 2 ? 2 : NBT <= 4 ? 4 : 8;
+    const int nb_max = CAK == 4 ? 4 : 2;                   // accumulators RBW * NB * 4 + fragments + prefetch slots inside 256 registers
+    const int NB = NBT < nb_max ? NBT : nb_max;
+    const int NP = NB * 16, CBP = dc_cbp(NP, P.S);
     P.M = 25 * P.CA;
-    const int nrb = (P.M + 15) / 16;
-    const int RBW = (nrb + DC_NW - 1) / DC_NW;            // 1 (CA 3), 2 (8), 4 (16), 7 (32)
-    P.RBW = RBW;
     P.TW = P.ws >= 64 ? 64 : P.ws >= 32 ? 32 : 16;
     P.tw_sh = P.TW == 64 ? 6 : P.TW == 32 ? 5 : 4;
-    // TH: the divisor-like height that keeps big halo + small tile inside the budget with the least halo overhead
+    // TH: the height that keeps big halo + small tile inside LDS and the prefetch slots with the least halo / ragged overhead
+    const size_t red = WK > 1 ? (size_t)(WK / 2) * WM * RBW * NB * 256 * 4 : 0;
     int best_th = 1;
     double best = -1;
     for (int th = 1; th <= 32; ++th) {
         const int ih = P.S * (th - 1) + 5, iw = P.S * (P.TW - 1) + 5;
         const size_t lds = (size_t)((ih * iw * CAP + 3) & ~3) * 4 + (size_t)th * P.TW * CBP * 4;
         if (lds > (size_t)LDS_BUDGET) break;
+        if ((int64_t)ih * iw * (CAK == 4 ? 3 : CAK / 4) > (int64_t)DC_THREADS * DC_PFB) break;
+        if ((int64_t)th * P.TW * (NP / 4) > (int64_t)DC_THREADS * dc_pfs(NB)) break;
         const int tiles = (P.hs + th - 1) / th;
-        const double eff = (double)P.hs / (tiles * th) * ((double)th / (th + 4.0 / P.S));
+        const int chunks = th * P.TW / 16, per_wave = (chunks + WK - 1) / WK;       // K chunks per wave: whole rounds over the WK groups
+        const double eff = (double)P.hs / (tiles * th) * ((double)th / (th + 4.0 / P.S)) * ((double)chunks / (per_wave * WK));
         if (eff > best) { best = eff; best_th = th; }
     }
     P.TH = best_th;
@@ -248,27 +279,33 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
     P.tiles_y = (P.hs + P.TH - 1) / P.TH;
     P.tiles_x = (P.ws + P.TW - 1) / P.TW;
     P.ntiles = P.nimg * P.tiles_y * P.tiles_x;
-    const size_t lds = (size_t)((P.IH * P.IW * CAP + 3) & ~3) * 4 + (size_t)P.TH * P.TW * CBP * 4;
-    // persistent blocks, as many per CU as LDS admits (up to 3): one block's tile loads run under another's MFMA loop
-    int occ = (int)((size_t)LDS_BUDGET / lds);
-    occ = occ < 1 ? 1 : occ > 3 ? 3 : occ;
-    int64_t nblk = 256 * occ;
+    size_t lds = (size_t)((P.IH * P.IW * CAP + 3) & ~3) * 4 + (size_t)P.TH * P.TW * CBP * 4;
+    if (lds < red) lds = red;
+    // persistent blocks, one per CU (8 waves, 150-250 registers), in whole rounds over the tiles
+    int64_t nblk = NUM_CU;
     const int64_t cap = slab_floats / ((int64_t)P.M * NP);
     if (nblk > cap) nblk = cap;
     if (nblk > P.ntiles) nblk = P.ntiles;
     if (nblk < 1) nblk = 1;
+    {
+        const int64_t rounds = (P.ntiles + nblk - 1) / nblk;
+        nblk = (P.ntiles + rounds - 1) / rounds;
+    }
     P.slab = slab;
     const dim3 grid((unsigned)nblk);
-#define DC_WG(cak, rbw) launch_wg_nb<cak, rbw>(s, P, NB, grid, lds)
-    if (CAK == 4) DC_WG(4, 1);
-    else if (CAK == 8) DC_WG(8, 2);
-    else if (CAK == 16) DC_WG(16, 4);
-    else DC_WG(32, 7);
+    for (int n0 = 0; n0 < P.CB; n0 += NP) {
+        P.n0 = n0;
+#define DC_WG(ss)                                                            \
+        if (CAK == 4) launch_wg_nb<4, 5, 1, ss>(s, P, NB, grid, lds);        \
+        else if (CAK == 8) launch_wg_nb<8, 7, 2, ss>(s, P, NB, grid, lds);   \
+        else if (CAK == 16) launch_wg_nb<16, 7, 4, ss>(s, P, NB, grid, lds); \
+        else launch_wg_nb<32, 7, 8, ss>(s, P, NB, grid, lds);
+        if (P.S == 1) { DC_WG(1) } else { DC_WG(2) }
 #undef DC_WG
-    const int64_t total = (int64_t)P.M * P.CB;
-    int64_t rb = (total + 255) / 256;
-    if (rb > 1024) rb = 1024;
-    hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float*)slab, (int)nblk, P.M, NP, P.CB, P.out);
+        const int ncols = P.CB - n0 < NP ? P.CB - n0 : NP;
+        const int rb = (P.M * NP / 4 + 15) / 16;
+        hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float4*)slab, (int)nblk, P.M, NP, ncols, n0, P.CB, P.out);
+    }
 }
 
 }  // namespace ctx

@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
         const int hl = L.kind == 0 ? L.hin / L.S : L.hin, wl = L.kind == 0 ? L.win / L.S : L.win;
         const double flops = 2.0 * L.nimg * (L.kind == 2 ? 4.0 * hl * wl * 6.25 : (double)hl * wl * 25) * L.CI * L.N;
         dconv_force_tile(0, 0, 0);
-        if (only >= 0) { run(); run(); run(); (void)hipStreamSynchronize(st); return 0; }
+        if (only >= 0) { run(); run(); run(); (void)hipStreamSynchronize(st); continue; }
         const float t_auto = timeit();
         printf("%s  auto: TH %d TW %d MI %d NB*10+occ %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
                flops / t_auto / 1e9);
@@ -111,6 +111,42 @@ int main(int argc, char** argv) {
             printf("      TH %2d TW %2d MI %d  %.3f ms  %.1f TF/s\n", rs[bi].th, rs[bi].tw, rs[bi].mi, rs[bi].ms, flops / rs[bi].ms / 1e9);
             rs.erase(rs.begin() + bi);
         }
+        fflush(stdout);
+    }
+    if (only >= 0 && only < 100) return 0;
+    // ---- filter gradients (automatic tile only)
+    struct WL { const char* name; int CA, c1, CB, nimg, hb, wb, S; };
+    const WL wl[] = {
+        {"h0 dw    3 x 32   36x64 s1 x768", 3, 32, 32, 3 * B, 36, 64, 1},
+        {"h1 dw   32 x 16   36x64 s2 x768", 32, 16, 16, 3 * B, 36, 64, 2},
+        {"h2 dw   16 x 16   18x32 s1 x768", 16, 16, 16, 3 * B, 18, 32, 1},
+        {"h3 dw   16 x 8    18x32 s2 x768", 16, 8, 8, 3 * B, 18, 32, 2},
+        {"d_h1 dw 16 x 8|8  18x32 s2 x512", 16, 8, 16, 2 * B, 18, 32, 2},
+        {"d_h2 dw 16 x 16|16 18x32 s1 x512", 16, 16, 32, 2 * B, 18, 32, 1},
+        {"d_h3 dw 32 x 16|16 36x64 s2 x512", 32, 16, 32, 2 * B, 36, 64, 2},
+        {"d_h4 dw  3 x 32|32 36x64 s1 x512", 3, 32, 64, 2 * B, 36, 64, 1},
+    };
+    const int64_t slab_floats = 8ll << 20;
+    float* slab = dalloc((size_t)slab_floats, 0.f);
+    int wi = 99;
+    for (const WL& L : wl) {
+        ++wi;
+        if (only >= 100 && wi != only) continue;
+        DcWgrad W{};
+        W.big = x1; W.ldb = L.CA; W.CA = L.CA; W.s1 = out; W.ld1 = L.c1; W.c1 = L.c1; W.CB = L.CB;
+        if (L.c1 < L.CB) { W.s2 = x2; W.ld2 = L.CB - L.c1; W.nmod2 = B; }
+        W.hb = L.hb; W.wb = L.wb; W.hs = L.hb / L.S; W.ws = L.wb / L.S; W.nimg = L.nimg; W.S = L.S; W.pad = L.S == 1 ? 2 : 1; W.out = w;
+        dconv_wgrad(st, W, slab, slab_floats);
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) { printf("%s  FAILED\n", L.name); continue; }
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < 10; ++i) dconv_wgrad(st, W, slab, slab_floats);
+        (void)hipEventRecord(e1, st);
+        (void)hipStreamSynchronize(st);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        ms /= 10;
+        const double flops = 2.0 * L.nimg * (double)W.hs * W.ws * 25 * L.CA * L.CB;
+        printf("%s  %.3f ms  %.1f TF/s\n", L.name, ms, flops / ms / 1e9);
         fflush(stdout);
     }
     return 0;
