@@ -292,6 +292,7 @@ int dev_alloc(ctx_handle* h, T** p, int64_t count, bool whole_tensor = true) {
         if (r_ != CTX_OK) return r_; \
     } while (0)
 
+bool d_h4_direct(const ctx_handle* h, int c1, int c2, int hs, int ws, int stride);
 int alloc_buffers(ctx_handle* h) {
     const int64_t B = h->Bm, d = h->d, F = h->F;
     TRY(dev_alloc(h, &h->u8, 3 * B * h->npi));
@@ -324,7 +325,9 @@ int alloc_buffers(ctx_handle* h) {
         TRY(dev_alloc(h, &h->dE[k], 2 * B * pix * ch));
     }
     TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
-    TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
+    // d_h4's scatter product exists only where the direct 3-channel kernel (convt3.hip) does not run: the split-bf16 mode / odd shapes
+    if (!d_h4_direct(h, d, d, h->hh[1], h->ww[1], 2))
+        TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
     TRY(dev_alloc(h, &h->dout4, 2 * B * h->npi / 3 * 4));
     int64_t maxc = std::max<int64_t>(h->D0, F);
@@ -417,6 +420,7 @@ const char* const K_FCDX = "igemm<KmPlain,KmPlain>";
 const char* const K_FCDW = "igemm<NmPlain,NmPlain>";
 const char* const K_CONVT3 = "convt3_gather";
 const char* const K_CONVT3P = "igemm<Cat2,KmPlain>";
+const char* const K_CONVT3D = "convt3_direct";
 const char* const K_COLSUM = "colsum";
 const char* const K_EW = "elementwise";
 
@@ -430,8 +434,20 @@ KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nul
 // the 3-channel edge layers (h0_conv forward / filter gradient, d_h4 input / filter gradient) on the direct kernels of dconv.h:
 // the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack passes go away
 // (measured at B = 256, 64x64: NOT faster than the 4-channel-copy implicit GEMM -- 14.9 vs 14.5 ms per step -- so off by default: CTX_DCONV_C3=1)
-bool use_dc3() { static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return e && e[0] == '1'; }(); return on; }
+// ContextSkipNew's 3-channel layers (h0_conv, d_h4's input and filter gradients) on the direct kernels of dconv.h: exact-f32 mode
+// only (the split-bf16 mode keeps the implicit GEMM on its 4-channel copies).  Measured on the persistent / prefetching dconv
+// kernels: 0.99 -> 0.71 ms of layer time per step, and no pack3to4 passes.  CTX_DCONV_C3=0 restores the implicit GEMM.
+bool use_dc3(const ctx_handle* h) {
+    static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return !(e && e[0] == '0'); }();
+    return on && h->cfg.precision == CTX_PREC_F32;
+}
 
+// d_h4 (conv2d_transpose to the 3 image channels) in one pass on the vector ALUs (convt3.hip) instead of scatter product + gather.
+// Exact-f32 mode only.  CTX_CONVT3_DIRECT=0 restores the two-step route (and its P3 buffer).
+bool d_h4_direct(const ctx_handle* h, int c1, int c2, int hs, int ws, int stride) {
+    static const bool on = [] { const char* e = getenv("CTX_CONVT3_DIRECT"); return !(e && e[0] == '0'); }();
+    return on && h->cfg.precision == CTX_PREC_F32 && convt3_direct_ok(c1, c2, hs, ws, stride);
+}
 bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
 
 int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = getenv("CTX_Q_MINPOS"); return e ? atoi(e) : -1; }(); return v >= 0 ? v : (h->cfg.precision ? 0 : 64); }
@@ -443,7 +459,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
-    if (ca == 3 && use_dc3()) {
+    if (ca == 3 && use_dc3(h)) {
         DcFwd P{};
         P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
         dconv_conv(h->stream, P, 2, 1);
@@ -540,7 +556,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
     float* src_z = h->Z + 2ll * B * F;
     const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
     // refresh the 4-channel copy of the frames in use (what the cin = 3 loaders read)
-    if (use_dc3()) {}
+    if (use_dc3(h)) {}
     else if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
     else pack_c4(h, h->img + B * npi, (mode == MODE_ENCODE ? 1ll : 2ll) * B * h->H * h->W);
     if (lanes) {
@@ -582,10 +598,15 @@ void forward(ctx_handle* h, int B, Mode mode) {
             dec = h->e[k];
         } else {
             const int R = nd * hs * ws;
-            { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl);
-              convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
-            { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
-              convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
+            if (d_h4_direct(h, c1, c2, hs, ws, 2)) {
+                ProfScope ps(h, nm_ + " fwd", K_CONVT3D, fl);
+                convt3_direct(h->stream, dec, c1, skip, c2, B, nd, hs, ws, 2, w, b, h->out);
+            } else {
+                { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl);
+                  convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
+                { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
+                  convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
+            }
         }
     }
 }
@@ -602,7 +623,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     {
         ProfScope ps(h, "losses", K_EW, 0.0);
         losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
-        if (!use_dc3()) pack_c4(h, h->dout, 2ll * B * h->H * h->W);
+        if (!use_dc3(h)) pack_c4(h, h->dout, 2ll * B * h->H * h->W);
     }
 
     // ---- decoder, both passes at once (batch 2B)
@@ -625,7 +646,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         Epi ed;
         ed.out1 = d_dec; ed.ld1 = c1; ed.nsplit = c1; ed.mask = dec_in; ed.ldm = c1;
         ed.out2 = h->dSk[4 - k]; ed.ld2 = c2;
-        if (ca == 3 && use_dc3()) {
+        if (ca == 3 && use_dc3(h)) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
               ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl);
@@ -710,7 +731,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 Side sd(h, dw_lane);
                 bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
-                if (use_dc3()) {
+                if (use_dc3(h)) {
                     DcWgrad Wg{};
                     Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
                     Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = nimg; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
@@ -794,6 +815,16 @@ int forward_inference(ctx_handle* h, int B, Mode mode) {
 int check_B(ctx_handle* h, int B) {
     if (!h) return CTX_E_INVALID;
     if (B <= 0 || B > h->Bm) return fail(h, CTX_E_INVALID, "B=%d outside [1, max_batch=%d]", B, h->Bm);
+    return CTX_OK;
+}
+
+// Device -> pageable host in pieces of 16 MiB.  Measured (tools/encode_cliff.py): one hipMemcpyAsync of 24.6 MB runs at
+// 55 GB/s, one of 36.9 MB at 10 GB/s (the runtime leaves its staged path above ~32 MB) -- the "B = 1000 cliff" of ctx_encode,
+// which hands 49 MB of float frames back.  Pieces keep every size on the fast path.
+int copy_d2h(ctx_handle* h, void* dst, const void* src, size_t bytes) {
+    constexpr size_t PIECE = 16u << 20;
+    for (size_t o = 0; o < bytes; o += PIECE)
+        HIP_TRY(h, hipMemcpyAsync((char*)dst + o, (const char*)src + o, bytes - o < PIECE ? bytes - o : PIECE, hipMemcpyDeviceToHost, h->stream));
     return CTX_OK;
 }
 
@@ -1077,7 +1108,7 @@ static int arena_io(ctx_handle* h, int slot, float* host, const float* chost, si
         return CTX_OK;
     }
     if (chost) HIP_TRY(h, hipMemcpyAsync(dev, chost, n * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    else HIP_TRY(h, hipMemcpyAsync(host, dev, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    else TRY(copy_d2h(h, host, dev, n * sizeof(float)));
     return finish(h);
 }
 
@@ -1124,7 +1155,7 @@ int ctx_init_params(ctx_handle* h, uint64_t seed) {
 
 static int translate_tail(ctx_handle* h, int B, float* pred, float* feat) {
     TRY(forward_inference(h, B, MODE_TRANSLATE));
-    if (pred) HIP_TRY(h, hipMemcpyAsync(pred, h->out, (size_t)B * h->npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (pred) TRY(copy_d2h(h, pred, h->out, (size_t)B * h->npi * sizeof(float)));
     if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z, h->Fp * sizeof(float), h->F * sizeof(float), B,
                                          hipMemcpyDeviceToHost, h->stream));
     h->last_B = 0;
@@ -1197,7 +1228,7 @@ int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* 
     TRY(forward_inference(h, B, MODE_ENCODE));
     if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
                                          hipMemcpyDeviceToHost, h->stream));
-    if (frames_f32) HIP_TRY(h, hipMemcpyAsync(frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (frames_f32) TRY(copy_d2h(h, frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float)));
     h->last_B = 0;
     return finish(h);
 }
@@ -1364,8 +1395,8 @@ int ctx_eval(ctx_handle* h, const float* src, const float* ctxf, const float* tg
     h->last_B = B;
     const size_t bytes = (size_t)B * h->npi * sizeof(float);
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
-    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out) TRY(copy_d2h(h, out, h->out, bytes));
+    if (out2) TRY(copy_d2h(h, out2, h->out + B * h->npi, bytes));
     return finish(h);
 }
 
@@ -1557,8 +1588,8 @@ int ctx_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* cho
     h->last_B = B;
     const size_t bytes = (size_t)B * h->npi * sizeof(float);
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
-    if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out) TRY(copy_d2h(h, out, h->out, bytes));
+    if (out2) TRY(copy_d2h(h, out2, h->out + B * h->npi, bytes));
     return finish(h);
 }
 
@@ -1567,7 +1598,7 @@ int ctx_last_outputs(ctx_handle* h, float* out, float* out2, float* tgt) {
     if (h->last_B <= 0) return fail(h, CTX_E_STATE, "no training-mode forward has run");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)h->last_B * h->npi * sizeof(float);
-    if (out) HIP_TRY(h, hipMemcpyAsync(out, h->out, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (out) TRY(copy_d2h(h, out, h->out, bytes));
     if (out2) HIP_TRY(h, hipMemcpyAsync(out2, h->out + (int64_t)h->last_B * h->npi, bytes, hipMemcpyDeviceToHost, h->stream));
     if (tgt) HIP_TRY(h, hipMemcpyAsync(tgt, h->img, bytes, hipMemcpyDeviceToHost, h->stream));   // img = [tgt | src | ctx]
     return finish(h);

@@ -55,6 +55,12 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   
 // conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
 // product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a
 // gather of the <= 9 taps that land on each output pixel (deterministic, no atomics).
+// The same layer in ONE pass on the vector ALUs (convt3.hip): input halo tile in LDS by 8-channel slices, a lane owns a column of
+// output rows; nothing between input and output.  The exact-f32 path of every 3-channel d_h4; the product + gather pair below
+// remains for the split-bf16 mode and for shapes convt3_direct_ok refuses.
+bool convt3_direct_ok(int c1, int c2, int hin, int win, int stride);
+void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int c2, int nmod2, int nimg, int hin, int win, int stride,
+                   const float* w, const float* bias, float* out);
 constexpr int P3_LD = 80;                   // row stride of P (75 used)
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);

@@ -237,14 +237,25 @@ class Translator:
         self._ck(self._lib.ctx_encode_f32(self._h, _fp(fr), fr.shape[0], _fp(feat)))
         return feat
 
-    def encode(self, frames, return_frames=True):
-        """frames uint8 [B,H,W,3] -> (input_z f32 [B,featsize], image_trans[0] f32 [B,H,W,3])."""
+    def encode(self, frames, return_frames=True, out=None):
+        """frames uint8 [B,H,W,3] -> (input_z f32 [B,featsize], image_trans[0] f32 [B,H,W,3]).
+
+        out = (feat, frames_f32): caller-owned result arrays to fill instead of fresh ones.  Above 32 MB (B >= 683 at 64x64) a
+        fresh numpy array is a fresh mmap whose pages fault in while the copy lands -- 4 ms of a 7.5 ms call at B = 1000
+        (tools/encode_cliff.py); a caller that encodes many paths per call should hand the same buffers back in."""
         fr = _u8(frames)
         if fr.ndim != 4 or fr.shape[1:] != (self.H, self.W, 3):
             raise ValueError(f"frames must be [B,{self.H},{self.W},3], got {fr.shape}")
         B = fr.shape[0]
-        feat = np.empty((B, self.featsize), np.float32)
-        f32 = np.empty(fr.shape, np.float32) if return_frames else None
+        if out is not None:
+            feat, f32 = out
+            if feat.shape != (B, self.featsize) or feat.dtype != np.float32 or not feat.flags.c_contiguous:
+                raise ValueError("out[0] must be a C-contiguous float32 [B, featsize] array")
+            if return_frames and (f32 is None or f32.shape != fr.shape or f32.dtype != np.float32 or not f32.flags.c_contiguous):
+                raise ValueError("out[1] must be a C-contiguous float32 array of the frames' shape")
+        else:
+            feat = np.empty((B, self.featsize), np.float32)
+            f32 = np.empty(fr.shape, np.float32) if return_frames else None
         self._ck(self._lib.ctx_encode(self._h, _up(fr), B, _fp(feat), _fp(f32) if return_frames else None))
         return feat, f32
 
