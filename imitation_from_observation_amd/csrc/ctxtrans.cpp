@@ -818,9 +818,9 @@ int check_B(ctx_handle* h, int B) {
     return CTX_OK;
 }
 
-// Device -> pageable host in pieces of 16 MiB.  Measured (tools/encode_cliff.py): one hipMemcpyAsync of 24.6 MB runs at
-// 55 GB/s, one of 36.9 MB at 10 GB/s (the runtime leaves its staged path above ~32 MB) -- the "B = 1000 cliff" of ctx_encode,
-// which hands 49 MB of float frames back.  Pieces keep every size on the fast path.
+// Device -> pageable host, in pieces of 16 MiB so that no single transfer leaves the runtime's staged path.  (The "B = 1000
+// cliff" of ctx_encode -- 49 MB of float frames handed back -- turned out NOT to be this copy: it was the caller's fresh > 32 MB
+// numpy array faulting its pages in while the copy landed; tools/encode_cliff.py, Translator.encode(out=...).)
 int copy_d2h(ctx_handle* h, void* dst, const void* src, size_t bytes) {
     constexpr size_t PIECE = 16u << 20;
     for (size_t o = 0; o < bytes; o += PIECE)
