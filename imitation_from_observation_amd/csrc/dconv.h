@@ -242,14 +242,16 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
     }
     const bool active = wv < nrb;
 
-    int ncol[NB], ncl[NB], nmk[NB];
-    float bias_v[NB];
+    // The products are formed TRANSPOSED (filter fragment as the MFMA's A operand, pixels as B): a lane then holds, per 16 x 16
+    // block, FOUR CONSECUTIVE CHANNELS n = n0 + 16 nb + 4 kg + {0..3} of ONE pixel (x = l15) -- one 16-byte store (and one 16-byte
+    // load per epilogue term) per lane and block instead of four 4-byte ones; the scalar stores of the first version were
+    // issue-bound (~7 B/clk/CU) on the wide, output-heavy layers.
+    int ncol[NB];
+    float4 bias_v[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        ncol[nb] = P.n0 + nb * 16 + l15;
-        ncl[nb] = ncol[nb] < P.N ? ncol[nb] : 0;                                        // a column that exists, for loads whose value is then unused
-        nmk[nb] = ncol[nb] < P.N && ncol[nb] < P.ep.nsplit ? ncol[nb] : 0;
-        bias_v[nb] = (P.ep.bias && ncol[nb] < P.N) ? P.ep.bias[ncol[nb]] : 0.f;
+        ncol[nb] = P.n0 + nb * 16 + 4 * kg;
+        bias_v[nb] = (P.ep.bias && ncol[nb] < P.N) ? ldg4(P.ep.bias + ncol[nb]) : zero4();
     }
     int t = blockIdx.x;
     if (t < ntiles) issue(t);
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
                                 const float bv = tt == 0 ? b4[buf][nb].x : tt == 1 ? b4[buf][nb].y : tt == 2 ? b4[buf][nb].z : b4[buf][nb].w;
-                                acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[mi][nb], 0, 0, 0);
+                                acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[mi][nb], 0, 0, 0);      // D^T: rows = channels, cols = pixels
                             }
                         }
                     }
@@ -316,63 +318,57 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
             };
             if (wv + DC_NW * (MI - 1) < nrb) run(std::integral_constant<int, MI>{});
             else if constexpr (MI > 1) { if (active) run(std::integral_constant<int, MI - 1>{}); }
-            // ---- epilogue of this class.  D: col = l15, row = 4 * kg + r.  The terms an element needs from memory (skip-gradient
-            // adds, the saved activation behind lrelu') are loaded for a whole row block at once and only then applied: one
-            // latency per row block, not one per element (epi_store's load -> wait -> store chain took longer than the MFMA loop).
+            // ---- epilogue of this class.  D^T: a lane has channels ncol[nb] .. + 3 of pixel x = l15 of each of its row blocks.  The
+            // terms an element needs from memory (skip-gradient adds, the saved activation behind lrelu') are loaded for a whole row
+            // block first, branch-free, and only then applied (epi_store's load -> wait -> store chain per element took
+            // longer than the MFMA loop).
+            {
+                int64_t pix[MI];
+                bool okp[MI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int rb = wv + DC_NW * mi, ty = rb / rbw, txb = (rb - ty * rbw) * 16;
-                const int y = ty0 + ty;
-                if (rb >= nrb || y >= P.hlog) continue;
-                int64_t pix[4];
-                bool okx[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int x = tx0 + txb + 4 * kg + r;
-                    okx[r] = x < P.wlog;
-                    pix[r] = ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * (okx[r] ? x : 0) + cl.ox);
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int rb = wv + DC_NW * mi, ty = rb / rbw, x = tx0 + (rb - ty * rbw) * 16 + l15, y = ty0 + ty;
+                    okp[mi] = rb < nrb && y < P.hlog && x < P.wlog;
+                    pix[mi] = okp[mi] ? ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * x + cl.ox) : 0;   // (a pixel that exists)
                 }
-                float t1[4][NB], t2[4][NB], tm[4][NB];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                for (int mi = 0; mi < MI; ++mi) {
+                    float4 t1[NB], t2[NB], tm[NB];
+                    if (P.ep.add1) {
+                        const int64_t pa = (P.ep.add1_mod && pix[mi] >= P.ep.add1_mod) ? pix[mi] - P.ep.add1_mod : pix[mi];
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) { t1[r][nb] = 0.f; t2[r][nb] = 0.f; tm[r][nb] = 1.f; }
-                if (P.ep.add1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t pa = (P.ep.add1_mod && pix[r] >= P.ep.add1_mod) ? pix[r] - P.ep.add1_mod : pix[r];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) t1[r][nb] = P.ep.add1[pa * P.ep.lda1 + ncl[nb]];      // (branch-free: clamped column, unused lanes are never stored)
+                        for (int nb = 0; nb < NB; ++nb) t1[nb] = ldg4(P.ep.add1 + pa * P.ep.lda1 + (ncol[nb] < P.N ? ncol[nb] : 0));
                     }
-                }
-                if (P.ep.add2) {
+                    if (P.ep.add2) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) t2[r][nb] = P.ep.add2[pix[r] * P.ep.lda2 + ncl[nb]];
-                }
-                if (P.ep.mask) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                        for (int nb = 0; nb < NB; ++nb) t2[nb] = ldg4(P.ep.add2 + pix[mi] * P.ep.lda2 + (ncol[nb] < P.N ? ncol[nb] : 0));
+                    }
+                    if (P.ep.mask) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            tm[r][nb] = P.ep.mask[pix[r] * P.ep.ldm + nmk[nb]];
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (!okx[r]) continue;
+                            tm[nb] = ldg4(P.ep.mask + pix[mi] * P.ep.ldm + (ncol[nb] < P.N && ncol[nb] < P.ep.nsplit ? ncol[nb] : 0));
+                    }
+                    if (!okp[mi]) continue;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int n = ncol[nb];
                         if (n >= P.N) continue;
-                        float v = acc[mi][nb][r] + bias_v[nb] + t1[r][nb];
-                        v += t2[r][nb];
-                        if (P.ep.lrelu) v = fmaxf(v, (P.ep.lrelu == 2 ? 0.f : LEAK) * v);
+                        float v[4] = {acc[mi][nb][0] + bias_v[nb].x, acc[mi][nb][1] + bias_v[nb].y, acc[mi][nb][2] + bias_v[nb].z, acc[mi][nb][3] + bias_v[nb].w};
+                        if (P.ep.add1) { v[0] += t1[nb].x; v[1] += t1[nb].y; v[2] += t1[nb].z; v[3] += t1[nb].w; }
+                        if (P.ep.add2) { v[0] += t2[nb].x; v[1] += t2[nb].y; v[2] += t2[nb].z; v[3] += t2[nb].w; }
+                        if (P.ep.lrelu) {
+                            const float lk = P.ep.lrelu == 2 ? 0.f : LEAK;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lk * v[r]);
+                        }
                         if (n < P.ep.nsplit) {
-                            if (P.ep.mask) v *= tm[r][nb] >= 0.f ? 1.f : LEAK;
-                            P.ep.out1[pix[r] * P.ep.ld1 + n] = v;
+                            if (P.ep.mask) {
+                                v[0] *= tm[nb].x >= 0.f ? 1.f : LEAK; v[1] *= tm[nb].y >= 0.f ? 1.f : LEAK;
+                                v[2] *= tm[nb].z >= 0.f ? 1.f : LEAK; v[3] *= tm[nb].w >= 0.f ? 1.f : LEAK;
+                            }
+                            *reinterpret_cast<float4*>(P.ep.out1 + pix[mi] * P.ep.ld1 + n) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
-                            P.ep.out2[pix[r] * P.ep.ld2 + (n - P.ep.nsplit)] = v;
+                            *reinterpret_cast<float4*>(P.ep.out2 + pix[mi] * P.ep.ld2 + (n - P.ep.nsplit)) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }
                 }

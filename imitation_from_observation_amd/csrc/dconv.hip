@@ -48,7 +48,8 @@ int g_dc_force[3] = {0, 0, 0};       // TH, TW, MI
 void dconv_force_tile(int th, int tw, int mi) { g_dc_force[0] = th; g_dc_force[1] = tw; g_dc_force[2] = mi; }
 int g_dc_last[4] = {0, 0, 0, 0};     // TH, TW, MI, GT of the last forward launch
 
-bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 32 || CI == 64) && N >= 1 && N <= 128; }
+// (N, the column split and every row stride of the epilogue's tensors in multiples of 4: the epilogue moves float4s)
+bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 32 || CI == 64) && N >= 4 && N <= 128 && N % 4 == 0; }
 
 // Fills tiles / LDS split and launches.  `span` = extent of the tap offsets (5 for the 5x5 taps over the input, 3 for a
 // stride-2 transposed conv over its small grid).
