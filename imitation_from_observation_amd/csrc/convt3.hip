@@ -5,8 +5,8 @@
 // P[pixel][tap * 3 + c] (75 columns, 168-377 MB through HBM) followed by a gather of the taps that land on each output pixel --
 // moved 4-8x the bytes of the tensors involved.  This kernel computes the layer directly on the vector ALUs, ONE pass over the
 // input, nothing in between:
-//   * a block owns an output tile; the input halo tile is staged in LDS in slices of 8 channels (pixel stride 12 floats: the
-//     ds_read_b128 of 16 consecutive pixels are conflict-free), the slice of the filter ([tap][c][8 k]) beside it; the next
+//   * a block owns an output tile; the input halo tile is staged in LDS in slices of 16 channels (pixel stride 20 floats: the
+//     ds_read_b128 of 16 consecutive pixels are conflict-free), the slice of the filter ([tap][c][16 k]) beside it; the next
 //     slice's global loads are in flight (registers) under the current slice's arithmetic;
 //   * a lane owns P consecutive output ROWS of one column (stride 2: the 2 x 2 output pixels of P small-grid rows x 1 column):
 //     for a filter column kx it reads the P + 4 (stride 2: P + 2) input vectors of its column once and uses them for every row
@@ -16,20 +16,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "launch.h"
 
 namespace ctx {
 
 namespace {
 
-constexpr int KS = 8;                 // channels per staged slice
-constexpr int PS = 12;                // LDS pixel stride in floats (KS + 4)
-constexpr int CT3_PF = 12;            // prefetch slots (float4) per thread: IH * IW * 2 <= threads * CT3_PF
+// Channels per staged slice, by stride.  16 at stride 1 (ContextAEReal: 64 B of a pixel's 128-B line per pass; with 8 the kernel
+// fetched 4x its tensors -- every line once per slice, gone from L2 by the next -- and was bound by that: 0.257 -> 0.227 ms).
+// 8 at stride 2 (ContextSkipNew: 48 accumulators per lane; the wider slice's prefetch registers cost more than the re-fetch:
+// 0.19 ms with 8, 0.27 ms with 16).  LDS pixel stride KS + 4 floats: 16 consecutive pixels' ds_read_b128 hit 16 distinct 4-bank slots.
+__host__ __device__ constexpr int ct3_ks(int S) { return S == 1 ? 16 : 8; }
+__host__ __device__ constexpr int ct3_pf(int S) { return S == 1 ? 16 : 6; }   // prefetch slots (float4) per thread: IH * IW * KS / 4 <= threads * this
 
 struct Ct3 {
     const float* x1; int c1;                       // decoder stream [nimg][hin][win][c1]
     const float* x2; int c2; int nmod2;            // ctx skip [nmod2][hin][win][c2], image index img % nmod2
-    int CI;                                        // c1 + c2, a multiple of 8; c1 a multiple of 8
+    int CI;                                        // c1 + c2; c1 and c2 multiples of KS
     int hin, win, nimg;
     const float* w;                                // [25][3][CI]  (the reference's [5,5,out,in])
     const float* bias;                             // [3]
@@ -44,6 +50,8 @@ typedef float ct_f2 __attribute__((ext_vector_type(2)));     // one v_pk_fma_f32
 
 template <int S /* stride */, int P /* rows per lane */, int NT /* threads */>
 __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
+    constexpr int CT3_PF = ct3_pf(S);
+    constexpr int KS = ct3_ks(S), PS = KS + 4, KQ = KS / 4, WQ = 25 * 3 * KQ;      // slice channels, LDS pixel stride, float4s per pixel / per filter slice
     constexpr int HALO = S == 1 ? 2 : 1;           // stride 1: rows y - 2 .. y + 2; stride 2 (small grid): i - 1 .. i + 1
     constexpr int NR = P + 2 * HALO;               // input rows a lane touches per column
     constexpr int NACC = S == 1 ? P * 3 : 4 * P * 3;
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
     float* wsl = smem + ((A.IH * A.IW * PS + 3) & ~3);         // [25][4][KS]  (c = 3: unused row)
     const int tid = threadIdx.x;
     const int xl = tid % A.TW, rg = tid / A.TW;                // column in the tile, row group (P rows each)
-    const int ntile_e = A.IH * A.IW * (KS / 4);
+    const int ntile_e = A.IH * A.IW * KQ;
     const float bias0 = A.bias[0], bias1 = A.bias[1], bias2 = A.bias[2];
 
     for (int t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
         const float* s2 = A.x2 + (int64_t)(img % A.nmod2) * A.hin * A.win * A.c2;
 
         ct_u32x4 pf[CT3_PF];
-        ct_u32x4 wpf;
+        ct_u32x4 wpf[(WQ + NT - 1) / NT];
         auto issue = [&](int k0) {                             // slice [k0, k0 + KS) of the input tile and of the filter -> registers
             const bool first = k0 < A.c1;
             const float* sp = first ? s1 + k0 : s2 + (k0 - A.c1);
@@ -73,30 +81,34 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
 #pragma unroll
             for (int j = 0; j < CT3_PF; ++j) {
                 const int i = tid + j * NT;
-                const int pi = i >> 1, c = (i & 1) * 4;
+                const int pi = i / KQ, c = (i % KQ) * 4;
                 const int iy = pi / A.IW, ix = pi - iy * A.IW;
                 const int gy = y0 - HALO + iy, gx = x0 - HALO + ix;
                 const bool ok = i < ntile_e && (unsigned)gy < (unsigned)A.hin && (unsigned)gx < (unsigned)A.win;
                 const int pix = ok ? gy * A.win + gx : 0;      // halo lanes read a pixel that exists and are zeroed when they land
                 pf[j] = *reinterpret_cast<const ct_u32x4*>(sp + (int64_t)pix * ld + c);
             }
-            // filter slice: 25 taps x 3 channels x 8 k = 150 float4
-            const int tc = tid >> 1, c4 = (tid & 1) * 4;
-            wpf = tid < 150 ? *reinterpret_cast<const ct_u32x4*>(A.w + (int64_t)tc * A.CI + k0 + c4) : ct_u32x4{0u, 0u, 0u, 0u};
+            // filter slice: 25 taps x 3 channels x KS k
+#pragma unroll
+            for (int u = 0; u < (WQ + NT - 1) / NT; ++u) {
+                const int i = tid + u * NT, tc = i / KQ, c4 = (i % KQ) * 4;
+                wpf[u] = i < WQ ? *reinterpret_cast<const ct_u32x4*>(A.w + (int64_t)tc * A.CI + k0 + c4) : ct_u32x4{0u, 0u, 0u, 0u};
+            }
         };
         auto land = [&]() {
 #pragma unroll
             for (int j = 0; j < CT3_PF; ++j) {
                 const int i = tid + j * NT;
-                const int pi = i >> 1, c = (i & 1) * 4;
+                const int pi = i / KQ, c = (i % KQ) * 4;
                 const int iy = pi / A.IW, ix = pi - iy * A.IW;
                 const int gy = y0 - HALO + iy, gx = x0 - HALO + ix;
                 const bool ok = (unsigned)gy < (unsigned)A.hin && (unsigned)gx < (unsigned)A.win;
                 if (i < ntile_e) *reinterpret_cast<ct_u32x4*>(&tile[pi * PS + c]) = ok ? pf[j] : ct_u32x4{0u, 0u, 0u, 0u};
             }
-            if (tid < 150) {
-                const int tc = tid >> 1, tap = tc / 3, c = tc - tap * 3;
-                *reinterpret_cast<ct_u32x4*>(&wsl[(tap * 4 + c) * KS + (tid & 1) * 4]) = wpf;
+#pragma unroll
+            for (int u = 0; u < (WQ + NT - 1) / NT; ++u) {
+                const int i = tid + u * NT, tc = i / KQ, tap = tc / 3, c = tc - tap * 3;
+                if (i < WQ) *reinterpret_cast<ct_u32x4*>(&wsl[(tap * 4 + c) * KS + (i % KQ) * 4]) = wpf[u];
             }
         };
 
@@ -214,6 +226,7 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
 template <int S, int P, int NT>
 void launch_ct3(hipStream_t s, Ct3 A, int TW) {
     constexpr int HALO = S == 1 ? 2 : 1;
+    constexpr int KS = ct3_ks(S), PS = KS + 4, KQ = KS / 4, CT3_PF = ct3_pf(S);
     A.TW = TW;
     A.TR = NT / TW * P;
     A.IH = A.TR + 2 * HALO;
@@ -222,6 +235,7 @@ void launch_ct3(hipStream_t s, Ct3 A, int TW) {
     A.tiles_x = (A.win + A.TW - 1) / A.TW;
     A.ntiles = A.nimg * A.tiles_y * A.tiles_x;
     const size_t lds = (size_t)((A.IH * A.IW * PS + 3) & ~3) * 4 + 25 * 4 * KS * 4;
+    if (A.IH * A.IW * KQ > NT * CT3_PF || lds > 160 * 1024) { fprintf(stderr, "convt3: tile %d x %d does not fit\n", A.IH, A.IW); abort(); }
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute((const void*)convt3_kernel<S, P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
     int per_cu = (int)((160 * 1024) / (lds + 1024));
@@ -235,7 +249,7 @@ void launch_ct3(hipStream_t s, Ct3 A, int TW) {
 }  // namespace
 
 bool convt3_direct_ok(int c1, int c2, int hin, int win, int stride) {
-    if (c1 % KS || c2 % KS || (stride != 1 && stride != 2)) return false;
+    if ((stride != 1 && stride != 2) || c1 % ct3_ks(stride) || c2 % ct3_ks(stride)) return false;
     // prefetch slots: the chosen tile's IH * IW * 2 float4s must fit threads x CT3_PF (checked against the tiles used below)
     return win >= 16 && hin >= 4;
 }
@@ -248,10 +262,7 @@ void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int 
     A.w = w; A.bias = bias; A.out = out;
     const int TW = win >= 64 ? 64 : win >= 32 ? 32 : 16;
     if (stride == 1) {
-        // rows per tile = NT / TW * P: pick the combination that wastes the fewest rows of the last tile
-        if (hin % 18 == 0 && TW == 64) launch_ct3<1, 3, 384>(s, A, TW);                // 36 x 64 frames: two tiles of 18 rows
-        else if (TW == 64) launch_ct3<1, 4, 256>(s, A, TW);                            // 16 rows
-        else launch_ct3<1, 4, 256>(s, A, TW);                                          // TW 32: 32 rows; TW 16: 64 rows
+        launch_ct3<1, 3, 384>(s, A, TW);      // rows per tile = 384 / TW * 3: 18 at TW 64 (36 x 64 frames: two tiles), 36 at TW 32
     } else {
         if (TW == 64) launch_ct3<2, 2, 256>(s, A, TW);                                 // 8 small-grid rows
         else launch_ct3<2, 2, 256>(s, A, TW);                                          // TW 32: 16 rows (a 32 x 32 grid in two tiles); TW 16: 32
