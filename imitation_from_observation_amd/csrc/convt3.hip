@@ -60,7 +60,12 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
     float* wsl = smem + ((A.IH * A.IW * PS + 3) & ~3);         // [25][4][KS]  (c = 3: unused row)
     const int tid = threadIdx.x;
     const int xl = tid % A.TW, rg = tid / A.TW;                // column in the tile, row group (P rows each)
-    const int ntile_e = A.IH * A.IW * KQ;
+    // slot j of a thread = float4 tid + NT j of the slice's tile; its (row, column) by recurrence from the thread's first slot (a
+    // fixed step of rows / columns and one wrap) instead of two divisions per slot and slice
+    constexpr int SPX = NT / KQ;                               // pixels a slot step advances (NT and KQ powers of two or 384 / {2, 4})
+    const int qy = SPX / A.IW, rx = SPX - qy * A.IW;
+    const int e0 = tid / KQ, cth = (tid % KQ) * 4;
+    const int iyb = e0 / A.IW, ixb = e0 - iyb * A.IW;
     const float bias0 = A.bias[0], bias1 = A.bias[1], bias2 = A.bias[2];
 
     for (int t = blockIdx.x; t < A.ntiles; t += gridDim.x) {
@@ -78,15 +83,15 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
             const bool first = k0 < A.c1;
             const float* sp = first ? s1 + k0 : s2 + (k0 - A.c1);
             const int ld = first ? A.c1 : A.c2;
+            int iy = iyb, ix = ixb;
 #pragma unroll
             for (int j = 0; j < CT3_PF; ++j) {
-                const int i = tid + j * NT;
-                const int pi = i / KQ, c = (i % KQ) * 4;
-                const int iy = pi / A.IW, ix = pi - iy * A.IW;
                 const int gy = y0 - HALO + iy, gx = x0 - HALO + ix;
-                const bool ok = i < ntile_e && (unsigned)gy < (unsigned)A.hin && (unsigned)gx < (unsigned)A.win;
+                const bool ok = iy < A.IH && (unsigned)gy < (unsigned)A.hin && (unsigned)gx < (unsigned)A.win;
                 const int pix = ok ? gy * A.win + gx : 0;      // halo lanes read a pixel that exists and are zeroed when they land
-                pf[j] = *reinterpret_cast<const ct_u32x4*>(sp + (int64_t)pix * ld + c);
+                pf[j] = *reinterpret_cast<const ct_u32x4*>(sp + (int64_t)pix * ld + cth);
+                ix += rx; iy += qy;
+                if (ix >= A.IW) { ix -= A.IW; ++iy; }
             }
             // filter slice: 25 taps x 3 channels x KS k
 #pragma unroll
@@ -96,14 +101,14 @@ __global__ __launch_bounds__(NT) void convt3_kernel(const Ct3 A) {
             }
         };
         auto land = [&]() {
+            int iy = iyb, ix = ixb;
 #pragma unroll
             for (int j = 0; j < CT3_PF; ++j) {
-                const int i = tid + j * NT;
-                const int pi = i / KQ, c = (i % KQ) * 4;
-                const int iy = pi / A.IW, ix = pi - iy * A.IW;
                 const int gy = y0 - HALO + iy, gx = x0 - HALO + ix;
                 const bool ok = (unsigned)gy < (unsigned)A.hin && (unsigned)gx < (unsigned)A.win;
-                if (i < ntile_e) *reinterpret_cast<ct_u32x4*>(&tile[pi * PS + c]) = ok ? pf[j] : ct_u32x4{0u, 0u, 0u, 0u};
+                if (iy < A.IH) *reinterpret_cast<ct_u32x4*>(&tile[(e0 + j * SPX) * PS + cth]) = ok ? pf[j] : ct_u32x4{0u, 0u, 0u, 0u};
+                ix += rx; iy += qy;
+                if (ix >= A.IW) { ix -= A.IW; ++iy; }
             }
 #pragma unroll
             for (int u = 0; u < (WQ + NT - 1) / NT; ++u) {

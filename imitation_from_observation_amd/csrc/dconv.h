@@ -151,7 +151,6 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
         }
     }
 
-    const int ntile_e = CIK == 4 ? P.IH * P.IW * 3 : P.IH * P.IW * C4;      // elements (floats | float4s) of one input tile
     const int rowf = P.IW * 3;
     dc_u32x4 pf[CIK == 4 ? 1 : DC_PF];
     unsigned pf1[CIK == 4 ? DC_PF : 1];
@@ -160,19 +159,28 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
         const int tyi = t % P.tiles_y;
         img = t / P.tiles_y; ty0 = tyi * P.TH; tx0 = txi * P.TW;
     };
+    // Slot j of a thread is element tid + 512 j of the tile.  Its tile coordinates follow from the thread's first element by a
+    // recurrence (a fixed step of rows and columns, one wrap) -- NOT by dividing every index by the runtime tile width: with the
+    // divisions, address arithmetic was 4.5 VALU instructions per MFMA over the whole kernel (PMC) and took as long as the MFMA loop.
+    constexpr int SPX = CIK == 4 ? DC_THREADS : DC_THREADS / C4;             // floats (CIK 4) | pixels a slot step advances
+    const int roww = CIK == 4 ? rowf : P.IW;                                // floats | pixels per tile row
+    const int qy = SPX / roww, rx = SPX - qy * roww;
+    const int e0 = CIK == 4 ? tid : tid / C4, cth = CIK == 4 ? 0 : (tid % C4) * 4;
+    const int iyb = e0 / roww, ixb = e0 - iyb * roww;
     auto issue = [&](int t) {                                // global loads of tile t -> prefetch registers
         int img, ty0, tx0;
         tile_org(t, img, ty0, tx0);
         const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
+        int iy = iyb, ix = ixb;
         if constexpr (CIK == 4) {
             const rsrc_t rs = make_rsrc(P.x1 + (int64_t)img * P.hin * P.win * 3);
 #pragma unroll
             for (int j = 0; j < DC_PF; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int iy = i / rowf, f = i - iy * rowf;
-                const int gy = iy0 + iy, gx3 = ix0 * 3 + f;
-                const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx3 < (unsigned)(P.win * 3);
+                const int gy = iy0 + iy, gx3 = ix0 * 3 + ix;      // (ix counts floats of the row here)
+                const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx3 < (unsigned)(P.win * 3);
                 pf1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.win * 3 + gx3) * 4) : OOB, 0, 0);
+                ix += rx; iy += qy;
+                if (ix >= roww) { ix -= roww; ++iy; }
             }
         } else {
             // one source: buffer loads, out-of-image lanes at the out-of-range marker.  Two sources ([decoder | ctx skip]): the
@@ -183,51 +191,50 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
                 const rsrc_t rs1 = make_rsrc(s1);
 #pragma unroll
                 for (int j = 0; j < DC_PF; ++j) {
-                    const int i = tid + j * DC_THREADS;
-                    const int pi = i / C4, c = (i - pi * C4) * 4;
-                    const int iy = pi / P.IW, ix = pi - iy * P.IW;
                     const int gy = iy0 + iy, gx = ix0 + ix;
-                    const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
-                    pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? (uint32_t)(((gy * P.win + gx) * P.ld1 + c) * 4) : OOB, 0, 0);
+                    const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
+                    pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? (uint32_t)(((gy * P.win + gx) * P.ld1 + cth) * 4) : OOB, 0, 0);
+                    ix += rx; iy += qy;
+                    if (ix >= roww) { ix -= roww; ++iy; }
                 }
             } else {
                 const float* s2 = P.x2 + (int64_t)(img % P.nmod2) * P.hin * P.win * P.ld2;
+                const float* sp = cth < P.c1 ? s1 + cth : s2 + (cth - P.c1);
+                const int ld = cth < P.c1 ? P.ld1 : P.ld2;
 #pragma unroll
                 for (int j = 0; j < DC_PF; ++j) {
-                    const int i = tid + j * DC_THREADS;
-                    const int pi = i / C4, c = (i - pi * C4) * 4;
-                    const int iy = pi / P.IW, ix = pi - iy * P.IW;
                     const int gy = iy0 + iy, gx = ix0 + ix;
-                    const bool ok = i < ntile_e && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
+                    const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
                     const int pix = ok ? gy * P.win + gx : 0;
-                    const float* p = c < P.c1 ? s1 + (int64_t)pix * P.ld1 + c : s2 + (int64_t)pix * P.ld2 + (c - P.c1);
-                    pf[j] = *reinterpret_cast<const dc_u32x4*>(p);
+                    pf[j] = *reinterpret_cast<const dc_u32x4*>(sp + (int64_t)pix * ld);
+                    ix += rx; iy += qy;
+                    if (ix >= roww) { ix -= roww; ++iy; }
                 }
             }
         }
     };
-    // (two-source tiles: whether slot j of tile t is a halo lane outside the image -- recomputed when it lands)
-    auto halo = [&](int t, int j) {
-        int img, ty0, tx0;
-        tile_org(t, img, ty0, tx0);
-        const int i = tid + j * DC_THREADS, pi = i / C4, iy = pi / P.IW, ix = pi - iy * P.IW;
-        const int gy = P.S * ty0 + P.y_org + iy, gx = P.S * tx0 + P.x_org + ix;
-        return !((unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win);
-    };
     auto land = [&](int t) {                                  // prefetch registers -> LDS tile
+        int iy = iyb, ix = ixb;
         if constexpr (CIK == 4) {
 #pragma unroll
             for (int j = 0; j < DC_PF; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
-                if (i < ntile_e) tile[(iy * P.IW + ix) * 4 + ch] = __uint_as_float(pf1[j]);
+                const int px = ix / 3, ch = ix - px * 3;
+                if (iy < P.IH) tile[(iy * P.IW + px) * 4 + ch] = __uint_as_float(pf1[j]);
+                ix += rx; iy += qy;
+                if (ix >= roww) { ix -= roww; ++iy; }
             }
         } else {
+            int img, ty0, tx0;
+            tile_org(t, img, ty0, tx0);
+            const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
+            const int lds0 = e0 * CIP + cth;
 #pragma unroll
             for (int j = 0; j < DC_PF; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int pi = i / C4, c = (i - pi * C4) * 4;
-                if (i < ntile_e) *reinterpret_cast<dc_u32x4*>(&tile[pi * CIP + c]) = (P.x2 && halo(t, j)) ? dc_u32x4{0u, 0u, 0u, 0u} : pf[j];
+                // (two-source tiles: halo lanes outside the image were loaded from a pixel that exists and become zeros here)
+                const bool halo = P.x2 && !((unsigned)(iy0 + iy) < (unsigned)P.hin && (unsigned)(ix0 + ix) < (unsigned)P.win);
+                if (iy < P.IH) *reinterpret_cast<dc_u32x4*>(&tile[lds0 + j * (SPX * CIP)]) = halo ? dc_u32x4{0u, 0u, 0u, 0u} : pf[j];
+                ix += rx; iy += qy;
+                if (ix >= roww) { ix -= roww; ++iy; }
             }
         }
     };
@@ -377,7 +384,9 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
             // bookkeeping cannot prove, across the loop back-edges, that the epilogue's loads into registers the next fragment
             // reads reuse are complete, and it puts an s_waitcnt vmcnt(0) in front of the first ds_read of the MFMA loop --
             // i.e. it waits for the NEXT tile's prefetch right after issuing it (seen in the ISA; the prefetch then hid nothing).
+#ifndef DC_NO_DRAIN
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
+#endif
         }
     }
 }
@@ -447,7 +456,6 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
         for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (CAK == 4) for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) bigt[i * 4 + 3] = 0.f;   // never loaded, never read as data (a < 3)
 
-    const int nbig_e = CAK == 4 ? P.IH * P.IW * 3 : P.IH * P.IW * C4;
     const int nsm_e = npix * S4;
     const int rowf = P.IW * 3;
     dc_u32x4 pb[CAK == 4 ? 1 : DC_PFB];
@@ -458,30 +466,36 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
         const int tyi = t % P.tiles_y;
         img = t / P.tiles_y; ty0 = tyi * P.TH; tx0 = txi * P.TW;
     };
+    // big-tile slot coordinates by recurrence from the thread's first element (see dconv_fwd_kernel: no division per slot)
+    constexpr int SPX = CAK == 4 ? DC_THREADS : DC_THREADS / C4;
+    const int roww = CAK == 4 ? rowf : P.IW;
+    const int qy = SPX / roww, rx = SPX - qy * roww;
+    const int e0 = CAK == 4 ? tid : tid / C4, cth = CAK == 4 ? 0 : (tid % C4) * 4;
+    const int iyb = e0 / roww, ixb = e0 - iyb * roww;
     auto issue = [&](int t) {
         int img, ty0, tx0;
         tile_org(t, img, ty0, tx0);
         const int iy0 = SS * ty0 - P.pad, ix0 = SS * tx0 - P.pad;
+        int iy = iyb, ix = ixb;
         if constexpr (CAK == 4) {
             const rsrc_t rs = make_rsrc(P.big + (int64_t)img * P.hb * P.wb * 3);
 #pragma unroll
             for (int j = 0; j < DC_PFB; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int iy = i / rowf, f = i - iy * rowf;
-                const int gy = iy0 + iy, gx3 = ix0 * 3 + f;
-                const bool ok = i < nbig_e && (unsigned)gy < (unsigned)P.hb && (unsigned)gx3 < (unsigned)(P.wb * 3);
+                const int gy = iy0 + iy, gx3 = ix0 * 3 + ix;
+                const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hb && (unsigned)gx3 < (unsigned)(P.wb * 3);
                 pb1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.wb * 3 + gx3) * 4) : OOB, 0, 0);
+                ix += rx; iy += qy;
+                if (ix >= roww) { ix -= roww; ++iy; }
             }
         } else {
             const rsrc_t rs = make_rsrc(P.big + (int64_t)img * P.hb * P.wb * P.ldb);
 #pragma unroll
             for (int j = 0; j < DC_PFB; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int pi = i / C4, c = (i - pi * C4) * 4;
-                const int iy = pi / P.IW, ix = pi - iy * P.IW;
                 const int gy = iy0 + iy, gx = ix0 + ix;
-                const bool ok = i < nbig_e && c < P.CA && (unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb;
-                pb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(((gy * P.wb + gx) * P.ldb + c) * 4) : OOB, 0, 0);
+                const bool ok = iy < P.IH && cth < P.CA && (unsigned)gy < (unsigned)P.hb && (unsigned)gx < (unsigned)P.wb;
+                pb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (uint32_t)(((gy * P.wb + gx) * P.ldb + cth) * 4) : OOB, 0, 0);
+                ix += rx; iy += qy;
+                if (ix >= roww) { ix -= roww; ++iy; }
             }
         }
         // small tile: zero outside the grid and past CB (those pixels / columns contribute nothing).  Two sources -> plain
@@ -504,19 +518,24 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
     auto land = [&](int t) {
         int img, ty0, tx0;
         tile_org(t, img, ty0, tx0);
-        if constexpr (CAK == 4) {
+        {
+            int iy = iyb, ix = ixb;
+            if constexpr (CAK == 4) {
 #pragma unroll
-            for (int j = 0; j < DC_PFB; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int iy = i / rowf, f = i - iy * rowf, ix = f / 3, ch = f - ix * 3;
-                if (i < nbig_e) bigt[(iy * P.IW + ix) * 4 + ch] = __uint_as_float(pb1[j]);
-            }
-        } else {
+                for (int j = 0; j < DC_PFB; ++j) {
+                    const int px = ix / 3, ch = ix - px * 3;
+                    if (iy < P.IH) bigt[(iy * P.IW + px) * 4 + ch] = __uint_as_float(pb1[j]);
+                    ix += rx; iy += qy;
+                    if (ix >= roww) { ix -= roww; ++iy; }
+                }
+            } else {
+                const int lds0 = e0 * CAP + cth;
 #pragma unroll
-            for (int j = 0; j < DC_PFB; ++j) {
-                const int i = tid + j * DC_THREADS;
-                const int pi = i / C4, c = (i - pi * C4) * 4;
-                if (i < nbig_e) *reinterpret_cast<dc_u32x4*>(&bigt[pi * CAP + c]) = pb[j];
+                for (int j = 0; j < DC_PFB; ++j) {
+                    if (iy < P.IH) *reinterpret_cast<dc_u32x4*>(&bigt[lds0 + j * (SPX * CAP)]) = pb[j];
+                    ix += rx; iy += qy;
+                    if (ix >= roww) { ix -= roww; ++iy; }
+                }
             }
         }
 #pragma unroll
