@@ -101,11 +101,13 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const DcFwd P, int NP, 
 // Out-of-image pixels are raw_buffer_loads at the out-of-range marker (the hardware returns zeros, no branch, no traffic).
 // Row block rb = wv + DC_NW * mi: the 8 waves all stay busy (latency hiding) and, waves w and w + 4 sharing SIMD w % 4, the
 // matrix pipes are evenly loaded whenever the tile has a multiple of 4 row blocks.
-constexpr int DC_PF = 12;
+constexpr int DC_PF = 12;           // prefetch slots per thread: the big-tile kernels (one block of 8 waves per CU, up to 256 registers)
+constexpr int DC_PF_SMALL = 4;      // ... and the kernels built for TWO blocks per CU (<= 128 registers): tiles of <= 2048 elements, so that one
+                                    // block's landing / epilogue / barriers run under the other's MFMA loop
 typedef unsigned dc_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int CIK, int MI, int NB>
-__global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
+template <int CIK, int MI, int NB, int PF = DC_PF>
+__global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv_fwd_kernel(const DcFwd P, int ntiles, int nslots) {
     const int CIP = P.CIP;                                 // (only in address set-up: the MFMA loop reads through abase[] + tab[])
     constexpr int NP = NB * 16;
     constexpr int TPC = CIK >= 16 ? 1 : 16 / CIK;          // taps per 16-k chunk
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
     }
 
     const int rowf = P.IW * 3;
-    dc_u32x4 pf[CIK == 4 ? 1 : DC_PF];
-    unsigned pf1[CIK == 4 ? DC_PF : 1];
+    dc_u32x4 pf[CIK == 4 ? 1 : PF];
+    unsigned pf1[CIK == 4 ? PF : 1];
     auto tile_org = [&](int t, int& img, int& ty0, int& tx0) {
         const int txi = t % P.tiles_x; t /= P.tiles_x;
         const int tyi = t % P.tiles_y;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
         if constexpr (CIK == 4) {
             const rsrc_t rs = make_rsrc(P.x1 + (int64_t)img * P.hin * P.win * 3);
 #pragma unroll
-            for (int j = 0; j < DC_PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 const int gy = iy0 + iy, gx3 = ix0 * 3 + ix;      // (ix counts floats of the row here)
                 const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx3 < (unsigned)(P.win * 3);
                 pf1[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.win * 3 + gx3) * 4) : OOB, 0, 0);
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
             if (!P.x2) {
                 const rsrc_t rs1 = make_rsrc(s1);
 #pragma unroll
-                for (int j = 0; j < DC_PF; ++j) {
+                for (int j = 0; j < PF; ++j) {
                     const int gy = iy0 + iy, gx = ix0 + ix;
                     const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
                     pf[j] = __builtin_amdgcn_raw_buffer_load_b128(rs1, ok ? (uint32_t)(((gy * P.win + gx) * P.ld1 + cth) * 4) : OOB, 0, 0);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
                 const float* sp = cth < P.c1 ? s1 + cth : s2 + (cth - P.c1);
                 const int ld = cth < P.c1 ? P.ld1 : P.ld2;
 #pragma unroll
-                for (int j = 0; j < DC_PF; ++j) {
+                for (int j = 0; j < PF; ++j) {
                     const int gy = iy0 + iy, gx = ix0 + ix;
                     const bool ok = iy < P.IH && (unsigned)gy < (unsigned)P.hin && (unsigned)gx < (unsigned)P.win;
                     const int pix = ok ? gy * P.win + gx : 0;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
         int iy = iyb, ix = ixb;
         if constexpr (CIK == 4) {
 #pragma unroll
-            for (int j = 0; j < DC_PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 const int px = ix / 3, ch = ix - px * 3;
                 if (iy < P.IH) tile[(iy * P.IW + px) * 4 + ch] = __uint_as_float(pf1[j]);
                 ix += rx; iy += qy;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_fwd_kernel(const DcFwd P, in
             const int iy0 = P.S * ty0 + P.y_org, ix0 = P.S * tx0 + P.x_org;
             const int lds0 = e0 * CIP + cth;
 #pragma unroll
-            for (int j = 0; j < DC_PF; ++j) {
+            for (int j = 0; j < PF; ++j) {
                 // (two-source tiles: halo lanes outside the image were loaded from a pixel that exists and become zeros here)
                 const bool halo = P.x2 && !((unsigned)(iy0 + iy) < (unsigned)P.hin && (unsigned)(ix0 + ix) < (unsigned)P.win);
                 if (iy < P.IH) *reinterpret_cast<dc_u32x4*>(&tile[lds0 + j * (SPX * CIP)]) = halo ? dc_u32x4{0u, 0u, 0u, 0u} : pf[j];

@@ -19,8 +19,16 @@ int cik_of(int CI) { return CI == 3 ? 4 : CI <= 8 ? 8 : CI <= 16 ? 16 : CI <= 32
 bool fwd_cfg_ok(int mi, int nb) { return nb == 1 ? mi <= 4 : nb == 2 ? mi <= 3 : nb == 4 ? mi <= 2 : false; }
 
 template <int CIK, int MI, int NB>
-void launch_fwd_one(hipStream_t s, const DcFwd& P, dim3 grid, size_t lds, int ntiles, int nslots) {
+void launch_fwd_one(hipStream_t s, const DcFwd& P, int occ, dim3 grid, size_t lds, int ntiles, int nslots) {
     if constexpr ((NB == 1 && MI <= 4) || (NB == 2 && MI <= 3) || (NB == 4 && MI <= 2)) {
+        if constexpr (MI * NB <= 2) {          // (MI x NB = 4 spills at 128 registers)
+            if (occ == 2) {                                   // the two-blocks-per-CU build (<= 128 registers, 4 prefetch slots)
+                static bool raised2 = false;
+                if (!raised2) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, NB, DC_PF_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / 2); raised2 = true; }
+                hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, NB, DC_PF_SMALL>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);
+                return;
+            }
+        }
         static bool raised = false;
         if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; }
         hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, NB>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);
@@ -28,23 +36,24 @@ void launch_fwd_one(hipStream_t s, const DcFwd& P, dim3 grid, size_t lds, int nt
 }
 
 template <int CIK, int MI>
-void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, dim3 grid, size_t lds, int ntiles, int nslots) {
-    if (NB == 4) launch_fwd_one<CIK, MI, 4>(s, P, grid, lds, ntiles, nslots);
-    else if (NB == 2) launch_fwd_one<CIK, MI, 2>(s, P, grid, lds, ntiles, nslots);
-    else launch_fwd_one<CIK, MI, 1>(s, P, grid, lds, ntiles, nslots);
+void launch_fwd_nb(hipStream_t s, const DcFwd& P, int NB, int occ, dim3 grid, size_t lds, int ntiles, int nslots) {
+    if (NB == 4) launch_fwd_one<CIK, MI, 4>(s, P, occ, grid, lds, ntiles, nslots);
+    else if (NB == 2) launch_fwd_one<CIK, MI, 2>(s, P, occ, grid, lds, ntiles, nslots);
+    else launch_fwd_one<CIK, MI, 1>(s, P, occ, grid, lds, ntiles, nslots);
 }
 
 template <int CIK>
-void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, dim3 grid, size_t lds, int ntiles, int nslots) {
-    if (MI == 4) launch_fwd_nb<CIK, 4>(s, P, NB, grid, lds, ntiles, nslots);
-    else if (MI == 3) launch_fwd_nb<CIK, 3>(s, P, NB, grid, lds, ntiles, nslots);
-    else if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, grid, lds, ntiles, nslots);
-    else launch_fwd_nb<CIK, 1>(s, P, NB, grid, lds, ntiles, nslots);
+void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, int occ, dim3 grid, size_t lds, int ntiles, int nslots) {
+    if (MI == 4) launch_fwd_nb<CIK, 4>(s, P, NB, occ, grid, lds, ntiles, nslots);
+    else if (MI == 3) launch_fwd_nb<CIK, 3>(s, P, NB, occ, grid, lds, ntiles, nslots);
+    else if (MI == 2) launch_fwd_nb<CIK, 2>(s, P, NB, occ, grid, lds, ntiles, nslots);
+    else launch_fwd_nb<CIK, 1>(s, P, NB, occ, grid, lds, ntiles, nslots);
 }
 }  // namespace
 
 // measurement hook (tools/dconv_bench.hip): force the tile of the next launches; 0 = automatic
 int g_dc_force[3] = {0, 0, 0};       // TH, TW, MI
+int g_dc_occ = [] { const char* e = getenv("CTX_DCONV_OCC"); return e ? atoi(e) : 0; }();   // 1: never two blocks per CU (A/B)
 void dconv_force_tile(int th, int tw, int mi) { g_dc_force[0] = th; g_dc_force[1] = tw; g_dc_force[2] = mi; }
 int g_dc_last[4] = {0, 0, 0, 0};     // TH, TW, MI, GT of the last forward launch
 
@@ -94,7 +103,10 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
                     for (int rb = 0; rb < nrb; ++rb) load[rb & 3] += 1;
                     int busiest = 1;
                     for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
-                    const int occ = 1;       // (the kernels take 110-250 registers: one block of 8 waves per CU)
+                    // two blocks per CU: both fit LDS, the tile fits the 4 prefetch slots of the <= 128-register build, few accumulators
+                    // (never at the price of extra column slices: measured slower on the 32-column layers)
+                    const int occ = (g_dc_occ != 1 && nb == (NBT > 4 ? 4 : NBT) && 2 * (tile + wall) + 1024 <= (size_t)LDS_TOTAL && mi * nb <= 2 &&
+                                     (int64_t)ih * iw * (CIK == 4 ? 3 : CIK / 4) <= (int64_t)DC_THREADS * DC_PF_SMALL) ? 2 : 1;
                     const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
                     const double rows = (double)P.hlog * P.wlog / ((double)tiles_y * tiles_x);          // real output pixels per tile
                     const double compute = (double)busiest * nb * 4.0 * nchunks * 32.0;
@@ -111,7 +123,8 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
         const size_t tile = (size_t)((ih * iw * CIP + 3) & ~3) * 4, wall = (size_t)nslots * CIK * best_nb * 16 * 4 + (size_t)(nslots * CIK / 16 + 1) * 16;
         g_dc_last[0] = 0;
         if (tile + wall > (size_t)LDS_BUDGET || (int64_t)ih * iw * (CIK == 4 ? 3 : CIK / 4) > (int64_t)DC_THREADS * DC_PF) return;
-        best_occ = 1;
+        best_occ = (g_dc_occ != 1 && best_nb == (NBT > 4 ? 4 : NBT) && 2 * (tile + wall) + 1024 <= (size_t)LDS_TOTAL && best_mi * best_nb <= 2 &&
+                    (int64_t)ih * iw * (CIK == 4 ? 3 : CIK / 4) <= (int64_t)DC_THREADS * DC_PF_SMALL) ? 2 : 1;
         if (!fwd_cfg_ok(best_mi, best_nb)) return;
     }
     P.TW = best_tw;
@@ -144,11 +157,11 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     for (int n0 = 0; n0 < P.N; n0 += NB * 16) {
         P.n0 = n0;
         switch (CIK) {
-            case 4: launch_fwd_mi<4>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-            case 8: launch_fwd_mi<8>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-            case 16: launch_fwd_mi<16>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-            case 32: launch_fwd_mi<32>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
-            default: launch_fwd_mi<64>(s, P, MI, NB, grid, lds, ntiles, nslots); break;
+            case 4: launch_fwd_mi<4>(s, P, MI, NB, best_occ, grid, lds, ntiles, nslots); break;
+            case 8: launch_fwd_mi<8>(s, P, MI, NB, best_occ, grid, lds, ntiles, nslots); break;
+            case 16: launch_fwd_mi<16>(s, P, MI, NB, best_occ, grid, lds, ntiles, nslots); break;
+            case 32: launch_fwd_mi<32>(s, P, MI, NB, best_occ, grid, lds, ntiles, nslots); break;
+            default: launch_fwd_mi<64>(s, P, MI, NB, best_occ, grid, lds, ntiles, nslots); break;
         }
     }
 }
