@@ -147,6 +147,14 @@ def test_inference_call_sites_match_oracle(T):
         of, ox = o.encode(p, fr[2], cfg)
         np.testing.assert_array_equal(x, ox)                 # preprocessing is bit-exact: three rounded f32 ops
         assert relmax(f, of) < 1e-4
+        # caller-owned result buffers (what a sampler that encodes many paths per call should pass): same bits, same arrays back
+        bf, bx = np.empty_like(f), np.empty_like(x)
+        rf, rx = tr.encode(fr[2], out=(bf, bx))
+        assert rf is bf and rx is bx
+        np.testing.assert_array_equal(bf, f)
+        np.testing.assert_array_equal(bx, x)
+        with pytest.raises(ValueError):
+            tr.encode(fr[2], out=(bf[:, :-1], bx))
         # ragged batches
         for b in (1, 7):
             pr, ft = tr.translate(fr[0][:b], fr[1][0])
