@@ -110,7 +110,7 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
                     const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
                     const double rows = (double)P.hlog * P.wlog / ((double)tiles_y * tiles_x);          // real output pixels per tile
                     const double compute = (double)busiest * nb * 4.0 * nchunks * 32.0;
-                    const double loadc = (double)tile / 16.0, land = (double)tile / 79.0, fixed = 700.0 + 40.0 * mi * nb * P.ncls;
+                    const double loadc = (double)tile / 16.0, land = (double)tile / 79.0, fixed = 3000.0 + 40.0 * mi * nb * P.ncls;   // (barriers, prefetch issue, epilogue: calibrated on the tile sweeps of tools/dconv_bench.hip)
                     const double T = (compute > loadc ? compute : loadc) + (land + fixed) / occ;
                     const double score = rows / (T * (NBT / nb));
                     if (score > best) { best = score; best_th = th; best_mi = mi; best_tw = tw; best_nb = nb; best_occ = occ; }
