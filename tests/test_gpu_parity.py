@@ -64,7 +64,8 @@ def load_golden(path):
 
 # ------------------------------------------------------------------------------- vs the oracle
 @pytest.mark.parametrize("H,W,d,F,B", [(32, 32, 32, 128, 4), (16, 48, 32, 128, 3), (48, 48, 32, 64, 2), (16, 16, 32, 32, 1),
-                                       (32, 32, 64, 256, 5)])
+                                       (32, 32, 64, 256, 5),
+                                       (64, 128, 32, 64, 2)])      # 64-wide small grid: the 64-column tiles of convt3 / dconv, two tiles per row
 def test_forward_backward_matches_oracle(T, H, W, d, F, B):
     cfg, p, fr = make_case(H, W, d, F, B)
     src, ctx, tgt = (o.preprocess_u8(x) for x in fr)

@@ -43,7 +43,8 @@ def test_param_inventory(T):
     assert [(n, s) for n, s, _ in info] == [(n, tuple(s)) for n, s in r.param_specs(cfg)]
 
 
-@pytest.mark.parametrize("H,W,B", [(36, 64, 3), (12, 8, 2), (16, 16, 5)])
+# (20, 128): two 64-column tiles per row in every direct kernel; (40, 64): a ragged last row tile (40 = 18 + 18 + 4 in convt3)
+@pytest.mark.parametrize("H,W,B", [(36, 64, 3), (12, 8, 2), (16, 16, 5), (20, 128, 2), (40, 64, 2)])
 def test_real_forward_backward_matches_oracle(T, H, W, B):
     cfg, p, fr = make(H, W, B)
     src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
