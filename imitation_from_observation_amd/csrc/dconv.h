@@ -386,7 +386,7 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
             // bookkeeping cannot prove, across the loop back-edges, that the epilogue's loads into registers the next fragment
             // reads reuse are complete, and it puts an s_waitcnt vmcnt(0) in front of the first ds_read of the MFMA loop --
             // i.e. it waits for the NEXT tile's prefetch right after issuing it (seen in the ISA; the prefetch then hid nothing).
-#ifndef DC_NO_DRAIN
+#ifndef DC_NO_DRAIN                                      // (A/B build of tools/dconv_bench.hip: the drain itself costs <= 2 %)
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
 #endif
         }
