@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/ctxtrans.h"
@@ -45,6 +46,9 @@ struct ctx_cnn {
     bool overlap = true;
     float* zeros = nullptr;
     bool stem4 = false;                               // buffer 0 is kept as [pixels][4] (see stem4_ok)
+    struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; };
+    std::map<int, GraphSlot> graphs;                  // one captured pass per image count (run_cached)
+    bool use_graphs = true;
     std::string err;
 };
 
@@ -175,6 +179,34 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
     if (hipGetLastError() != hipSuccess) return cfail(h, CTX_E_DEVICE, "kernel launch failed");
     return CTX_OK;
 }
+// The ~107 launches of a pass are 20-120 us each: captured into a hipGraph on the second pass with a given image count and
+// replayed afterwards (a kernel trace of the config-4 step showed the device idle ~9 % of the time between them).  Single-lane
+// passes only (the branch lanes of the split-bf16 mode keep plain launches); every pointer a launch captures is owned by the
+// handle.  CTX_GRAPHS=0 keeps plain launches.
+int run_cached(ctx_cnn* h, int n) {
+    if (!h->use_graphs || h->overlap) return run(h, n);
+    ctx_cnn::GraphSlot& g = h->graphs[n];
+    if (g.calls++ == 0) return run(h, n);                      // first pass: plain (code objects, LDS limits)
+    if (!g.exec) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(h->lane[0], hipStreamCaptureModeThreadLocal);
+        int rc = CTX_OK;
+        if (e == hipSuccess) {
+            rc = run(h, n);
+            e = hipStreamEndCapture(h->lane[0], &graph);
+        }
+        if (e == hipSuccess && rc == CTX_OK && graph) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess || rc != CTX_OK || !g.exec) {       // capture not possible here: stay on plain launches
+            (void)hipGetLastError();
+            g.exec = nullptr;
+            h->use_graphs = false;
+            return run(h, n);
+        }
+    }
+    if (hipGraphLaunch(g.exec, h->lane[0]) != hipSuccess) return cfail(h, CTX_E_DEVICE, "hipGraphLaunch failed");
+    return CTX_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -225,6 +257,7 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     if (ok) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     // measured at 192 images of 125x125: branch lanes -11 % in the split-bf16 mode, +2 % (and a slower chained train step) in f32
     { const char* e = getenv("CTX_CNN_LANES"); h->overlap = e ? e[0] != '0' : precision == CTX_PREC_BF16X3; }
+    { const char* e = getenv("CTX_GRAPHS"); h->use_graphs = !(e && e[0] == '0'); }
     alloc((void**)&h->zeros, 256, true);
     if (!ok) { cfail(nullptr, CTX_E_NOMEM, "device allocation failed"); ctx_cnn_destroy(h); return CTX_E_NOMEM; }
     *out = h;
@@ -241,6 +274,7 @@ void ctx_cnn_destroy(ctx_cnn* h) {
         if (h->slab[l]) (void)hipFree(h->slab[l]);
         if (l && h->lane[l]) { (void)hipStreamSynchronize(h->lane[l]); (void)hipStreamDestroy(h->lane[l]); }
     }
+    for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     for (hipEvent_t e : h->done) if (e) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -268,7 +302,7 @@ int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out) {
         const int m = n - i0 < h->max_images ? n - i0 : h->max_images;
         CNN_HIP(h, hipMemcpyAsync(h->u8, frames + (int64_t)i0 * pix_in * 3, (size_t)m * pix_in * 3, hipMemcpyHostToDevice, h->stream));
         pad_channels_u8(h->stream, h->u8, h->dbuf[0], m * pix_in, h->stem4 ? 4 : b0.c);
-        const int rc = run(h, m);
+        const int rc = run_cached(h, m);
         if (rc != CTX_OK) return rc;
         if (out) CNN_HIP(h, hipMemcpyAsync(out + (int64_t)i0 * per_out, h->dbuf.back(), (size_t)m * per_out * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         CNN_HIP(h, hipStreamSynchronize(h->stream));
@@ -283,7 +317,7 @@ int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** 
     CNN_HIP(h, hipSetDevice(h->device));
     const ctx_cnn_buf& b0 = h->bufs.front();
     pad_channels_f32(h->stream, d_frames, h->dbuf[0], (int64_t)n * b0.h * b0.w, h->stem4 ? 4 : b0.c);
-    const int rc = run(h, n);
+    const int rc = run_cached(h, n);
     if (rc != CTX_OK) return rc;
     if (d_out) *d_out = h->dbuf.back();
     return CTX_OK;
