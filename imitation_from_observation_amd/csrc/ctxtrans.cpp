@@ -729,12 +729,13 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
             if (k == 0) {
                 Side sd(h, dw_lane);
-                bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
+                if (!use_dc3(h)) bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);       // (dconv_wgrad returns the column sums of its small operand too)
                 ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
                 if (use_dc3(h)) {
                     DcWgrad Wg{};
                     Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
                     Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = nimg; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
+                    Wg.db = sc.gb[k];
                     dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats);
                 } else conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 break;   // no gradient w.r.t. the frame

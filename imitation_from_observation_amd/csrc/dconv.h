@@ -417,6 +417,9 @@ struct DcWgrad {
     int M;                                         // 25 * CA
     float* slab;                                   // [gridDim.x][M][NP]
     float* out;                                    // dw [25][CA][CB]
+    float* db;                                     // != nullptr: also the column sums of the SMALL tensor (= the bias gradient of a conv layer,
+                                                   // whose dy is the small operand) -- the tile is in LDS anyway; saves a pass over dy
+    float* dbslab;                                 // [gridDim.x][NP] partial column sums (behind the dw slabs)
 };
 
 constexpr int DC_PFB = 14;                         // prefetch slots per thread, big tile (float4s; floats of a [pixel][3] tensor)
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (CAK == 4) for (int i = tid; i < P.IH * P.IW; i += DC_THREADS) bigt[i * 4 + 3] = 0.f;   // never loaded, never read as data (a < 3)
+    float dbacc = 0.f;
 
     const int nsm_e = npix * S4;
     const int rowf = P.IW * 3;
@@ -557,6 +561,10 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
         land(t);
         __syncthreads();
         if (t + (int)gridDim.x < P.ntiles) issue(t + gridDim.x);
+        if (P.db) {                                          // column sums of the small tile (zeros outside the grid / past CB): thread = (column, pixel phase)
+            const int col = tid % NP, seg = tid / NP;
+            for (int p = seg; p < npix; p += DC_THREADS / NP) dbacc += smallt[p * CBP + col];
+        }
         // ---- K loop over this wave's share of the tile's pixels, 16 per chunk: lane group kg takes pixels c + 4 kg + tt.
         // Software-pipelined: the LDS reads of the wave's next chunk are issued before the MFMAs of the current one.
         // A lane's four pixels p0 .. p0 + 3 (p0 a multiple of 4, TW >= 16) sit in one tile row: one address per operand row,
@@ -602,6 +610,17 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_wgrad_kernel(const DcWgrad P
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) mma_tt(tt);
             }
+        }
+    }
+    // ---- bias gradient: the threads' partial column sums -> one per column, in a fixed order, -> this block's slab row
+    if (P.db) {
+        __syncthreads();                                     // tiles dead
+        smem[tid] = dbacc;                                   // [pixel phase][column]
+        __syncthreads();
+        if (tid < NP) {
+            float v = 0.f;
+            for (int sgi = 0; sgi < DC_THREADS / NP; ++sgi) v += smem[sgi * NP + tid];
+            P.dbslab[(int64_t)blockIdx.x * NP + tid] = v;
         }
     }
     // ---- the WK partial sums of a row block -> one, in a fixed tree through LDS (deterministic)

@@ -297,7 +297,7 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
     if (lds < red) lds = red;
     // persistent blocks, one per CU (8 waves, 150-250 registers), in whole rounds over the tiles
     int64_t nblk = NUM_CU;
-    const int64_t cap = slab_floats / ((int64_t)P.M * NP);
+    const int64_t cap = slab_floats / ((int64_t)(P.M + 1) * NP);         // (+ 1 row: the bias-gradient partials)
     if (nblk > cap) nblk = cap;
     if (nblk > P.ntiles) nblk = P.ntiles;
     if (nblk < 1) nblk = 1;
@@ -306,6 +306,7 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
         nblk = (P.ntiles + rounds - 1) / rounds;
     }
     P.slab = slab;
+    P.dbslab = slab + nblk * (int64_t)P.M * NP;
     const dim3 grid((unsigned)nblk);
     for (int n0 = 0; n0 < P.CB; n0 += NP) {
         P.n0 = n0;
@@ -319,6 +320,8 @@ void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
         const int ncols = P.CB - n0 < NP ? P.CB - n0 : NP;
         const int rb = (P.M * NP / 4 + 15) / 16;
         hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float4*)slab, (int)nblk, P.M, NP, ncols, n0, P.CB, P.out);
+        if (P.db)                                            // the same fixed-order sum over the blocks' partial column sums (one row of NP)
+            hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3(1), dim3(256), 0, s, (const float4*)P.dbslab, (int)nblk, 1, NP, ncols, n0, P.CB, P.db);
     }
 }
 
