@@ -33,6 +33,130 @@ PEAK_HBM = 8.0e12
 PEAK_BF16_MFMA = 2.5e15                            # dense; a split product costs 3 bf16 MFMA flops per algorithmic flop
 
 
+def csrc_sha16():
+    """Identity of the kernel sources this tree builds libctxtrans.so from: the PMC-derived traffic figures under profiles/
+    carry the hash of the sources they were measured on (tools/hbm_aggregate.py) and are only quoted for the same sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "imitation_from_observation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cpp")) +
+                    glob.glob(os.path.join(d, "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def real_flops_per_triple(H, W):
+    """Algorithmic fwd+bwd FLOPs of one ContextAEReal triple (arm_shaping.py:1611-1684: k 5, strides 1/2/1/2, filters 32/16/16/8,
+    featsize 100; 3 encoder images and 2 decoder passes per triple; backward = input gradient + filter gradient of every layer
+    except the first conv's input gradient)."""
+    nf, st, F = (32, 16, 16, 8), (1, 2, 1, 2), 100
+    h, w, cin, fwd, first = H, W, 3, 0.0, 0.0
+    grids = []
+    for k in range(4):
+        h, w = h // st[k], w // st[k]
+        fl = 2.0 * h * w * 25 * cin * nf[k]
+        fwd += 3 * fl
+        if k == 0:
+            first = 3 * fl
+        grids.append((h, w))
+        cin = nf[k]
+    d0 = grids[3][0] * grids[3][1] * nf[3]
+    fc = 3 * 2.0 * (d0 * F + F * F) + 2.0 * (2 * F * F + F * F) + 2 * 2.0 * F * d0
+    dec = 0.0
+    for k in range(1, 5):                                    # d_hk mirrors encoder layer 4-k: input grid = that layer's output grid
+        gi = 4 - k
+        hi, wi = grids[gi]
+        cout = nf[gi - 1] if gi else 3
+        dec += 2 * 2.0 * hi * wi * 25 * (2 * nf[gi]) * cout
+    fwd += fc + dec
+    return 3.0 * fwd - first
+
+
+def secondary_legs(device, steps=40):
+    """BASELINE configs[4] and [3] on one GPU, timed by this process (never `value`): (a) ContextAEReal 36x64, batch 256, fwd + bwd
+    + Adam, frames resident; (b) one GPU's share of config 4: 64 triples of 125x125 frames = 192 images through the frozen
+    Inception-v3 front end, then ContextAEInception2 fwd + bwd + Adam on the 2x2x2048 maps, one stream, everything resident."""
+    import torch
+    from imitation_from_observation_amd import Translator
+    out = {}
+    try:
+        Hh, Ww, Bb = 36, 64, 256
+        tr = Translator(Hh, Ww, featsize=100, max_batch=Bb, variant="real", device=device)
+        tr.init_params(0)
+        g = torch.Generator(device="cuda").manual_seed(7)
+        d = [(torch.randint(0, 256, (Bb, Hh, Ww, 3), device="cuda", generator=g, dtype=torch.uint8).float() / 127.5 - 1.0).contiguous()
+             for _ in range(3)]
+        torch.cuda.synchronize()
+        for _ in range(5):
+            tr.dev_forward_backward(*(t.data_ptr() for t in d), Bb)
+            tr.dev_adam(1e-4)
+        tr.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr.dev_forward_backward(*(t.data_ptr() for t in d), Bb)
+            tr.dev_adam(1e-4)
+        tr.sync()
+        dt = (time.perf_counter() - t0) / steps
+        fl = real_flops_per_triple(Hh, Ww) * Bb
+        out["context_ae_real_36x64_b256"] = {"ms_per_step": 1e3 * dt, "frames_per_s": Bb / dt, "steps": steps,
+                                             "gflop_per_step": fl / 1e9, "tflops": fl / dt / 1e12,
+                                             "frac_f32_mfma_peak": fl / dt / PEAK_F32_MFMA, "loss_after": tr.dev_scalars()["loss"]}
+        tr.close()
+    except Exception as e:                                   # a secondary leg must never cost the bench line
+        out["context_ae_real_36x64_b256"] = {"error": repr(e)[:300]}
+    try:
+        from imitation_from_observation_amd.inception_frontend import InceptionFrontend
+        S, Bc = 125, 64
+        g = torch.Generator(device="cuda").manual_seed(8)
+        frames = (torch.randint(0, 256, (3 * Bc, S, S, 3), device="cuda", generator=g, dtype=torch.uint8).float() / 127.5 - 1.0).contiguous()
+        stream = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        front = InceptionFrontend(S, S, max_images=3 * Bc, precision="f32", stream=stream.cuda_stream, device=device)
+        front.init_synthetic(0)
+        h, w, c = front.out_shape
+        tr = Translator(h, w, 64, 1024, max_batch=Bc, variant="inception2", C=c, precision="f32", stream=stream.cuda_stream, device=device)
+        tr.init_params(1)
+        lay = 0.0
+        for op, cv in zip([o_ for o_ in front._ops if o_["kind"] == 0], front.convs):
+            ho, wo = front._bufs[op["dst"]][:2]
+            lay += 2.0 * ho * wo * cv["k"][0] * cv["k"][1] * cv["cin"] * cv["cout"]
+        per = h * w * c * 4
+
+        def step():
+            dd = front.features_dev(frames.data_ptr(), 3 * Bc)
+            tr.dev_forward_backward(dd, dd + Bc * per, dd + 2 * Bc * per, Bc)
+            tr.dev_adam(1e-4)
+
+        for _ in range(3):
+            step()
+        tr.sync()
+        n = max(10, steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            front.features_dev(frames.data_ptr(), 3 * Bc)
+        front.sync()
+        tf_ = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        tr.sync()
+        dt = (time.perf_counter() - t0) / n
+        out["config4_share_64_triples_125x125"] = {
+            "ms_per_step": 1e3 * dt, "triples_per_s": Bc / dt, "steps": n,
+            "frontend_ms": 1e3 * tf_, "frontend_images_per_s": 3 * Bc / tf_, "frontend_gflop_per_image": lay / 1e9,
+            "frontend_tflops": lay * 3 * Bc / tf_ / 1e12, "frontend_frac_f32_mfma_peak": lay * 3 * Bc / tf_ / PEAK_F32_MFMA,
+            "translator_ms": 1e3 * (dt - tf_), "loss_after": tr.dev_scalars()["loss"],
+            "note": "synthetic Inception-v3 variables (the checkpoint is not in the reference tree), f32"}
+        tr.close()
+        front.close()
+    except Exception as e:
+        out["config4_share_64_triples_125x125"] = {"error": repr(e)[:300]}
+    return out
+
+
 def _median_min(ts):
     ts = sorted(ts)
     return ts[len(ts) // 2], ts[0]
@@ -224,6 +348,10 @@ def main():
                     help="arithmetic of the contractions: exact f32 MFMA (default) or split-bf16 products (DESIGN.md section 6b)")
     ap.add_argument("--no-split-leg", action="store_true",
                     help="skip the extra bf16x3 measurement that a default (f32) run appends as line['bf16x3']")
+    ap.add_argument("--sustained-s", type=float, default=3.0,
+                    help="after the timed run, keep stepping for at least this many seconds and report sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (ContextAEReal 36x64 B=256, config-4 share) a default 1-GPU run appends as line['secondary']")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # plain `python bench.py --gpus N`: start the ranks ourselves
@@ -290,6 +418,23 @@ def main():
 
     dt, scal, step_events = timed(trainer)
 
+    # Sustained leg (never `value`): the K timed steps are a fraction of a second; clocks settle to the power budget over seconds
+    # (MI355X_MICROARCH.md, DVFS), so the same step is run on for >= --sustained-s seconds and reported beside the contract's figure.
+    sustained = None
+    if args.sustained_s > 0:
+        n_sus = max(args.steps, int(args.sustained_s / (dt / args.steps)) + 1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            trainer.step(src, ctx, tgt, lr=1e-4)
+        barrier()
+        dts = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dts], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dts = float(tmax.item())
+        sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": 1e3 * dts / n_sus, "frames_per_s": n_sus * B * world / dts}
+
     ms = 1e3 * dt / args.steps
     value = args.steps * B * world / dt
     line = {
@@ -303,6 +448,7 @@ def main():
                    "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
                    "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
         "loss_after": scal["loss"],
+        "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
         "step_ms_hip_events": step_events,          # rank 0's stream; `ms_per_step` / `value` are the wall-clock mean, max over ranks
         "step_rates": {
             "tflops_f32": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / 1e12,
@@ -368,12 +514,24 @@ def main():
         import glob
         prof = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json" if args.precision == "f32" else f"*_hbm_traffic_{args.precision}.json")))
         if prof and B == 256:
-            with open(prof[-1]) as f:
-                tr_json = json.load(f)
-            ent = tr_json["per_kernel"].get(kname)
-            if ent:
-                line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_source"] = os.path.basename(prof[-1])
+            # newest file measured on THESE kernel sources (the file records the hash of csrc/ it was taken on); a file from
+            # another build is named but not quoted
+            sha = csrc_sha16()
+            line["roofline"]["csrc_sha16"] = sha
+            match = None
+            for pf in reversed(prof):
+                with open(pf) as f:
+                    tr_json = json.load(f)
+                if tr_json.get("csrc_sha16") == sha:
+                    match = (pf, tr_json)
+                    break
+            if match:
+                ent = match[1]["per_kernel"].get(kname)
+                if ent:
+                    line["roofline"]["traffic"] = ent["hbm_bytes_per_launch"]
+                    line["roofline"]["traffic_source"] = os.path.basename(match[0])
+            else:
+                line["roofline"]["traffic_stale_source"] = os.path.basename(prof[-1])
         line["kernels"] = {n: {"ms": round(t["ms"], 4), "launches": t["launches"],
                                "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None}
                            for n, t in tab.items()}
@@ -401,6 +559,12 @@ def main():
                               "note": "products a*b evaluated as hi*hi + hi*lo + lo*hi on bf16 MFMA with f32 accumulation "
                                       "(~1e-5 relative, tests/test_gpu_split.py); everything else f32"}
             del t2
+        if not args.no_secondary and world == 1 and args.precision == "f32":
+            try:
+                del trainer
+            except NameError:
+                pass
+            line["secondary"] = secondary_legs(local_rank)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(batch=32, steps=10)
         import ctypes

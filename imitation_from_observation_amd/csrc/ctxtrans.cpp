@@ -123,6 +123,7 @@ struct ctx_handle {
     float* dp_scal = nullptr;
     bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
     int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
+    int dp_rc = 0;                // result of the tail bucket's collective (started from inside backward)
 
     // per-op profiling (ctx_profile_step): HIP events around every launch group
     bool prof_on = false;
@@ -398,12 +399,12 @@ struct Side {
 constexpr int LANE_CTX = 0, LANE_DW = 1;
 
 // the tail of the gradient arena [first, Ppad) (translate/*, deconv/*: arena order is conv_context, conv, translate, deconv) is final
-void dp_reduce_range(ctx_handle* h, int64_t first, int64_t count);
+int dp_reduce_range(ctx_handle* h, int64_t first, int64_t count);
 void fire_bucket(ctx_handle* h, int64_t first) {
     if (!h->bucket_fn && !h->dp_in_step) return;
     if (use_lanes(h)) join(h, LANE_DW);          // their filter / bias gradients ran on the side lane
     if (h->dp_in_step) {                         // ctx_dp_train_step: the tail bucket goes out while the encoders' backward is enqueued
-        dp_reduce_range(h, first, h->Ppad - first);
+        h->dp_rc = dp_reduce_range(h, first, h->Ppad - first);      // (checked by ctx_dp_train_step after backward returns)
         h->dp_split = first;
         return;
     }
@@ -412,6 +413,7 @@ void fire_bucket(ctx_handle* h, int64_t first) {
 
 const char* const K_CONV = "igemm<ConvGather,Plain>";
 const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
+const char* const K_CONVT1 = "igemm<ConvGather,ConvTWeights>";   // stride-1 conv2d_transpose as a flipped correlation (convt1_fwd)
 const char* const K_WGRAD = "igemm<WgradBig,WgradSmall>";
 const char* const K_C3FWD = "igemm<C3Gather,C3Weights>";
 const char* const K_C3WGRAD = "igemm<C3WgradBig,WgradSmall>";
@@ -420,7 +422,11 @@ const char* const K_FCDX = "igemm<KmPlain,KmPlain>";
 const char* const K_FCDW = "igemm<NmPlain,NmPlain>";
 const char* const K_CONVT3 = "convt3_gather";
 const char* const K_CONVT3P = "igemm<Cat2,KmPlain>";
-const char* const K_CONVT3D = "convt3_direct";
+const char* const K_CONVT3D = "convt3_kernel";
+// the narrow-channel direct kernels of dconv.h (ContextSkipNew's 3-channel edge layers in f32, all of ContextAEReal's narrow path):
+// a launch group is labelled with the kernel that actually runs it
+const char* const K_DCFWD = "dconv_fwd_kernel";
+const char* const K_DCWGRAD = "dconv_wgrad_kernel";
 const char* const K_COLSUM = "colsum";
 const char* const K_EW = "elementwise";
 
@@ -429,17 +435,16 @@ thread_local const float* g_zeros = nullptr;   // 256 B of device zeros: where t
 NmPlain nm(const float* p, int64_t ld, int R, int K) { return NmPlain{p, ld, nullptr, 0, R, R, K, g_zeros}; }
 KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nullptr, 0, K, R, K / KC, g_zeros}; }
 
-// position-major launches (KmConvGatherQ / KmConvTGatherQ) pay once a block is mostly full: rows = images
-// (transposed conv on 4x4 grids: 64 problems of 1..9 taps leave a long tail; the class-major launch stays faster there)
-// the 3-channel edge layers (h0_conv forward / filter gradient, d_h4 input / filter gradient) on the direct kernels of dconv.h:
-// the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack passes go away
-// (measured at B = 256, 64x64: NOT faster than the 4-channel-copy implicit GEMM -- 14.9 vs 14.5 ms per step -- so off by default: CTX_DCONV_C3=1)
-// ContextSkipNew's 3-channel layers (h0_conv, d_h4's input and filter gradients) on the direct kernels of dconv.h: exact-f32 mode
-// only (the split-bf16 mode keeps the implicit GEMM on its 4-channel copies).  Measured on the persistent / prefetching dconv
-// kernels: 0.99 -> 0.71 ms of layer time per step, and no pack3to4 passes.  CTX_DCONV_C3=0 restores the implicit GEMM.
+// ContextSkipNew's 3-channel edge layers (h0_conv forward / filter gradient, d_h4's input and filter gradients) on the direct
+// kernels of dconv.h: the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack
+// passes go away.  ON by default in the exact-f32 mode (the split-bf16 mode keeps the implicit GEMM on its 4-channel copies):
+// measured on the persistent / prefetching dconv kernels 0.99 -> 0.71 ms of layer time per step.  CTX_DCONV_C3=0 restores the
+// implicit GEMM.  The direct forward kernel packs at most 128 filter columns (dconv_ok): d_h4's input gradient has N = 2 * df_dim
+// columns, so a handle with df_dim > 64 stays on the implicit GEMM for all of its 3-channel layers (decided per handle, because
+// the implicit GEMM needs the 4-channel copies refreshed by forward / backward).
 bool use_dc3(const ctx_handle* h) {
     static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return !(e && e[0] == '0'); }();
-    return on && h->cfg.precision == CTX_PREC_F32;
+    return on && h->cfg.precision == CTX_PREC_F32 && dconv_ok(3, h->d) && dconv_ok(3, 2 * h->d);
 }
 
 // d_h4 (conv2d_transpose to the 3 image channels) in one pass on the vector ALUs (convt3.hip) instead of scatter product + gather.
@@ -456,7 +461,7 @@ int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = ge
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
                 const float* b, float* y, int cb) {
     const int hs = hb / 2, ws = wb / 2, R = nimg * hs * ws;
-    ProfScope ps(h, name + " fwd", ca == 3 ? K_C3FWD : K_CONV, 2.0 * R * 25 * ca * cb);
+    ProfScope ps(h, name + " fwd", ca == 3 ? (use_dc3(h) ? K_DCFWD : K_C3FWD) : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
     if (ca == 3 && use_dc3(h)) {
@@ -649,12 +654,12 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         if (ca == 3 && use_dc3(h)) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
-              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl);
+              ProfScope ps(h, nm_ + " dw", K_DCWGRAD, fl);
               DcWgrad Wg{};
               Wg.big = dy; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dec_in; Wg.ld1 = c1; Wg.c1 = c1; Wg.s2 = h->c[4 - k]; Wg.ld2 = c2; Wg.nmod2 = B; Wg.CB = cb;
               Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = 2 * B; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
               dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats); }
-            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl);
+            { ProfScope ps(h, nm_ + " dx", K_DCFWD, fl);
               DcFwd D{};
               D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack;
               dconv_conv(h->stream, D, 2, 1); }
@@ -730,7 +735,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             if (k == 0) {
                 Side sd(h, dw_lane);
                 if (!use_dc3(h)) bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);       // (dconv_wgrad returns the column sums of its small operand too)
-                ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
+                ProfScope ps(h, ln + " dw", use_dc3(h) ? K_DCWGRAD : K_C3WGRAD, fl);
                 if (use_dc3(h)) {
                     DcWgrad Wg{};
                     Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
@@ -914,25 +919,29 @@ bool rccl_load() {
     } while (0)
 
 void dp_teardown(ctx_handle* h) {
+    if (h->dp_stream) (void)hipStreamSynchronize(h->dp_stream);      // no collective may still be in flight when its communicator goes
     if (h->dp_comm && rccl().lib) (void)rccl().CommDestroy(h->dp_comm);
     h->dp_comm = nullptr;
-    if (h->dp_stream) { (void)hipStreamSynchronize(h->dp_stream); (void)hipStreamDestroy(h->dp_stream); h->dp_stream = nullptr; }
+    if (h->dp_stream) { (void)hipStreamDestroy(h->dp_stream); h->dp_stream = nullptr; }
     if (h->dp_ev_ready) { (void)hipEventDestroy(h->dp_ev_ready); h->dp_ev_ready = nullptr; }
     if (h->dp_ev_done) { (void)hipEventDestroy(h->dp_ev_done); h->dp_ev_done = nullptr; }
 }
 
 // SUM all-reduce of grads[first, first + count) on the collective stream, ordered after everything the compute stream has
 // queued so far.  The compute stream is NOT made to wait here (dp_wait does that), so the collective overlaps what follows.
-void dp_reduce_range(ctx_handle* h, int64_t first, int64_t count) {
-    if (count <= 0) return;
+// Returns CTX_OK or a CTX_E_* code (message in h->err): a failed collective must never let Adam run on un-reduced gradients.
+int dp_reduce_range(ctx_handle* h, int64_t first, int64_t count) {
+    if (count <= 0) return CTX_OK;
     float* g = h->arena + h->Ppad + first;
-    (void)hipEventRecord(h->dp_ev_ready, h->stream);
-    (void)hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0);
-    (void)rccl().AllReduce(g, g, (size_t)count, ncclFloat, ncclSum, h->dp_comm, h->dp_stream);
+    HIP_TRY(h, hipEventRecord(h->dp_ev_ready, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0));
+    RCCL_TRY(h, rccl().AllReduce(g, g, (size_t)count, ncclFloat, ncclSum, h->dp_comm, h->dp_stream));
+    return CTX_OK;
 }
-void dp_wait(ctx_handle* h) {
-    (void)hipEventRecord(h->dp_ev_done, h->dp_stream);
-    (void)hipStreamWaitEvent(h->stream, h->dp_ev_done, 0);
+int dp_wait(ctx_handle* h) {
+    HIP_TRY(h, hipEventRecord(h->dp_ev_done, h->dp_stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->dp_ev_done, 0));
+    return CTX_OK;
 }
 }  // namespace
 
@@ -1469,6 +1478,15 @@ int ctx_dp_init(ctx_handle* h, const uint8_t id[CTX_DP_UNIQUE_ID_BYTES], int ran
         RCCL_TRY(h, rccl().Broadcast(p, p, (size_t)h->Ppad, ncclFloat, 0, h->dp_comm, h->dp_stream));
     }
     RCCL_TRY(h, rccl().GroupEnd());
+    // ... and rank 0's step counter (host state behind the bias correction of Adam): two floats carry its 48 low bits exactly
+    {
+        float t2[2] = {(float)(h->adam_t & 0xffffff), (float)((h->adam_t >> 24) & 0xffffff)};
+        HIP_TRY(h, hipMemcpyAsync(h->dp_scal, t2, sizeof t2, hipMemcpyHostToDevice, h->dp_stream));
+        RCCL_TRY(h, rccl().Broadcast(h->dp_scal, h->dp_scal, 2, ncclFloat, 0, h->dp_comm, h->dp_stream));
+        HIP_TRY(h, hipMemcpyAsync(t2, h->dp_scal, sizeof t2, hipMemcpyDeviceToHost, h->dp_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->dp_stream));
+        h->adam_t = (int64_t)t2[0] + ((int64_t)t2[1] << 24);
+    }
     HIP_TRY(h, hipStreamSynchronize(h->dp_stream));
     return CTX_OK;
 }
@@ -1485,8 +1503,8 @@ int ctx_dp_allreduce_grads(ctx_handle* h) {
     if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
     if (!h->have_grads) return fail(h, CTX_E_STATE, "no backward has run");
     HIP_TRY(h, hipSetDevice(h->device));
-    dp_reduce_range(h, 0, h->Ppad);
-    dp_wait(h);
+    TRY(dp_reduce_range(h, 0, h->Ppad));
+    TRY(dp_wait(h));
     HIP_TRY(h, hipGetLastError());
     return CTX_OK;
 }
@@ -1503,12 +1521,13 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     forward(h, B, MODE_TRAIN);
     // two buckets: [split, Ppad) = translate/* + deconv/* leaves from inside backward (fire_bucket) and travels while the
     // encoders' backward runs; [0, split) = the encoders after it.  simloss is a mean over the GLOBAL batch (arm_shaping.py:1345).
-    h->dp_in_step = true; h->dp_split = -1;
+    h->dp_in_step = true; h->dp_split = -1; h->dp_rc = CTX_OK;
     backward(h, B, B * h->dp_world);
     h->dp_in_step = false;
+    TRY(h->dp_rc);
     const int64_t split = h->dp_split >= 0 ? h->dp_split : h->Ppad;
-    dp_reduce_range(h, 0, split);
-    dp_wait(h);
+    TRY(dp_reduce_range(h, 0, split));
+    TRY(dp_wait(h));
     TRY(adam_step(h, lr));
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
@@ -1521,8 +1540,8 @@ int ctx_dp_scalars(ctx_handle* h, float scalars[4]) {
     if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
     HIP_TRY(h, hipSetDevice(h->device));
     // {loss, simloss, recon1, recon2} of this rank's shard -> global: recon sums add, simloss is the mean of equal shards
-    (void)hipEventRecord(h->dp_ev_ready, h->stream);
-    (void)hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0);
+    HIP_TRY(h, hipEventRecord(h->dp_ev_ready, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->dp_stream, h->dp_ev_ready, 0));
     RCCL_TRY(h, rccl().AllReduce(h->scalars, h->dp_scal, 4, ncclFloat, ncclSum, h->dp_comm, h->dp_stream));
     float s[4];
     HIP_TRY(h, hipMemcpyAsync(s, h->dp_scal, sizeof s, hipMemcpyDeviceToHost, h->dp_stream));

@@ -23,7 +23,9 @@ What differs, and why:
     models).  Its intended meaning -- for every output j the index of the nearest tgt frame, compared with j % nlen -- is
     computed on the host from `out` and the tgt slot for every model;
   * clips are stored as uint8 arrays `__<k>trans.npy` / `__<k>recon.npy` (imageio absent), same frames the gifs would hold;
-  * the tabular log is a CSV `<basedir>progress.csv` (rllab's logger is outside the hot path).
+  * the tabular log is a CSV `<basedir>progress.csv` (rllab's logger is outside the hot path).  As in the reference, on a
+    save iteration its R1 / R2 columns hold the LAST CLIP's recon1 / recon2 (the clip loop re-uses the names, :192-193),
+    while Loss / Sim / NNErr stay the validation batch's.
 Random draws come from the global `np.random` in the reference's order, so a seeded run samples the same batches.
 """
 from __future__ import annotations
@@ -54,7 +56,10 @@ def on_u8_lattice(vdata):
     if v.dtype == np.uint8:
         return v, True
     k = np.rint((v.astype(np.float64) + 1.0) * 127.5)
-    if k.min() < 0 or k.max() > 255 or np.abs(k / 127.5 - 1.0 - v).max() > 1e-6:
+    if k.min() < 0 or k.max() > 255:
+        return None, False
+    # exact: the f32 value the session is fed must BE the device table's entry  float32(k / 127.5 - 1)  (ctx_demos_upload)
+    if not np.array_equal((k / 127.5 - 1.0).astype(np.float32), v.astype(np.float32)):
         return None, False
     return k.astype(np.uint8), True
 
@@ -122,7 +127,9 @@ class ModelTrainer:
         u8, lattice = on_u8_lattice(vdata) if not self.inception else (None, False)
         resident = lattice and hasattr(tr, "load_demos")
         if resident:
-            tr.load_demos(u8)
+            # only frames t < nlen are ever sampled (t = b % nlen, and frame 0 for the context); the device sampler takes
+            # t = b % T with T = the uploaded tensor's length, so upload exactly nlen frames (vdata may hold more)
+            tr.load_demos(np.ascontiguousarray(u8[:nlen]))
 
         def train_step(cs, ct):
             if resident:
@@ -173,6 +180,8 @@ class ModelTrainer:
                             choicesrc = [np.random.randint(nvalid)] * B
                             choicetgt = [np.random.randint(nvalid)] * B
                             clip, _ = evaluate(choicesrc, choicetgt)
+                            r1, r2 = clip["recon1"], clip["recon2"]           # the reference's clip fetch overwrites r1 / r2 (:192-193): the
+                                                                              # tabular R1 / R2 of a save iteration are the last clip's
                             for tag, frames in (("trans", clip["out"]), ("recon", clip["out2"])):
                                 u = (np.clip((frames[:nlen] + 1.0) / 2.0, 0, 1) * 255).astype(np.uint8)     # savegif's frames (:23-26)
                                 np.save("%s%d/__%d%s" % (basedir, itr, kk, tag), u)

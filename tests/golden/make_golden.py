@@ -126,6 +126,72 @@ def make_real(tag, cfg, B, pseed, stddev, frames, steps, lr=1e-4):
     print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
 
 
+def make_incep2(tag, cfg, B, pseed, stddev, fseed, steps, lr=1e-4):
+    """Same contents for ContextAEInception2 (oracle/ctx_oracle_incep.py) on synthetic post-ReLU feature maps [B,h,w,C]:
+    the class takes strides / kernels / filters (arm_shaping.py:1786-1803), so the fixture carries them."""
+    from oracle import ctx_oracle_incep as ci
+    p = ci.init_params(cfg, pseed, np.float64, stddev=stddev)
+    brng = np.random.default_rng(pseed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * stddev
+    frng = np.random.default_rng(fseed)
+    src, ctx, tgt = (np.maximum(frng.standard_normal((B, cfg.H, cfg.W, cfg.C)), 0.0).astype(np.float32).astype(np.float64) for _ in range(3))
+    fx = dict(cfg=np.array([cfg.H, cfg.W, cfg.C, cfg.featsize]), strides=np.array(cfg.strides), kernels=np.array(cfg.kernels),
+              filters=np.array(cfg.filters), B=B, pseed=pseed, stddev=stddev, fseed=fseed, lr=lr, steps=steps,
+              src_f32=src.astype(np.float32), ctx_f32=ctx.astype(np.float32), tgt_f32=tgt.astype(np.float32))
+    fx["param_digest"], _ = digest(ci.flatten(p, cfg))
+    res, c = ci.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        fx[k] = res[k].astype(np.float32)
+    fx["scalars"] = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]])
+    g = ci.backward(p, c, cfg)
+    names = [n for n, _ in ci.param_specs(cfg)]
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_head"] = np.stack([np.pad(digest(g[n])[1], (0, N_HEAD - min(N_HEAD, g[n].size))) for n in names])
+    pred, feat = ci.translate(p, src, ctx[0], cfg)
+    fx["translate_pred"], fx["translate_feat"] = pred.astype(np.float32), feat.astype(np.float32)
+    fx["encode_feat"] = ci.encode(p, src, cfg).astype(np.float32)
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    traj = []
+    for t in range(1, steps + 1):
+        rr, cc = ci.forward(p, src, ctx, tgt, cfg)
+        o.adam_step(p, ci.backward(p, cc, cfg), m, v, t, lr)
+        traj.append([rr["loss"], rr["simloss"], rr["recon1"], rr["recon2"]])
+    fx["train_scalars"] = np.array(traj)
+    path = os.path.join(HERE, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(tag, os.path.getsize(path), "bytes; loss", res["loss"])
+
+
+def make_inception_v3(tag, pseed, fseed, B, S):
+    """Inception-v3 to Mixed_7c (nets/inception_v3.py:93-416) on the oracle's synthetic variables (seeded; the checkpoint is not
+    in the reference tree): the Mixed_7c feature maps whole, a digest + head of each of the 18 end points."""
+    from oracle import inception_oracle as io
+    p = io.init_params(pseed)
+    frames = np.random.default_rng(fseed).integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    ep = io.forward(p, o.preprocess_u8(frames).astype(np.float64))
+    fx = dict(pseed=pseed, fseed=fseed, B=B, S=S, frames_u8=frames, endpoints=np.array(list(ep)),
+              Mixed_7c=ep["Mixed_7c"].astype(np.float32),
+              endpoint_digest=np.stack([digest(v)[0] for v in ep.values()]),
+              endpoint_head=np.stack([digest(v)[1] for v in ep.values()]))
+    fx["param_digest"], _ = digest(np.concatenate([np.asarray(v).reshape(-1) for v in p.values()]))
+    path = os.path.join(HERE, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(tag, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "extra":
+    from oracle import ctx_oracle_incep as ci
+    # ContextAEInception2 as the unmodified reference class can be built: featsize 1024 (hard-coded, :1797), free strides /
+    # kernels / filters.  One case with the sampler's [1,2,1,2] / [3,3,3,3], one with other strides and kernel sizes.
+    make_incep2("incep2_4x4x64_f32_b2", ci.Incep2Config(H=4, W=4, C=64, filters=(32, 32, 32, 32)), 2, 555, 0.05, 9, steps=2)
+    make_incep2("incep2_8x4x32_k5331_s2121_b2", ci.Incep2Config(H=8, W=4, C=32, strides=(2, 1, 2, 1), kernels=(5, 3, 3, 1),
+                                                                 filters=(32, 64, 32, 32)), 2, 556, 0.05, 10, steps=2)
+    make_inception_v3("inception_v3_125x125_b2", 0, 3, 2, 125)
+
+
 if __name__ == "__main__" and len(sys.argv) == 1:
     from oracle import ctx_oracle_real as r
     # ContextAEReal at the reference's sweep imsize (run_trpo_sweep_ours.py:64)

@@ -1,5 +1,6 @@
 """Recipe that would PIN the oracle on the reference itself: import the reference's own model classes
-(gym/envs/mujoco/arm_shaping.py: ContextSkipNew :1260-1354, ContextAEReal :1599-1684) under TensorFlow 1.x, feed them the
+(gym/envs/mujoco/arm_shaping.py: ContextSkipNew :1260-1354, ContextAEReal :1599-1684, ContextAEInception2 :1786-1894; and
+nets/inception_v3.py:93-416 to Mixed_7c) under TensorFlow 1.x, feed them the
 inputs and parameters of the committed oracle fixtures, and write the reference's outputs in the SAME .npz schema
 (tests/golden/make_golden.py: make / make_real) as  tests/golden/tf_<tag>.npz -- or, with --check, compare them with the
 committed oracle fixtures and print the deviations.
@@ -10,7 +11,8 @@ environment.yml lists them) plus a checkout of the reference:
 
     REFERENCE_ROOT=/path/to/imitation_from_observation  python tests/golden/make_tf_fixtures.py [--check]
 
-Until someone runs it, the oracle stays "parity unpinned" (oracle/ctx_oracle.py header).  Nothing from
+Until someone runs it, the oracle stays "parity unpinned" (oracle/ctx_oracle.py header).  Once
+tests/golden/tf_*.npz exist, tests/test_tf_pin.py (CPU) checks every array in them against the oracle's fixtures (<= 1e-4).  Nothing from
 the reference is copied: the script loads the module from REFERENCE_ROOT at run time and only stores arrays.
 """
 import argparse
@@ -91,6 +93,78 @@ def run_reference(mod, cls_name, p, frames_u8, lr, steps):
     return out
 
 
+def run_reference_incep2(mod, z, p):
+    """ContextAEInception2(strides, kernels, filters).build(image) on float feature maps [3,B,h,w,C] (arm_shaping.py:1786-1894;
+    train_script.py:110-121 builds it on featreshape): same fetches as run_reference, no uint8 path (image_trans IS the input)."""
+    import tensorflow as tf
+    tf1 = tf.compat.v1 if hasattr(tf, "compat") and hasattr(tf.compat, "v1") else tf
+    tf1.reset_default_graph()
+    src, ctx, tgt = (np.asarray(z[k], np.float32) for k in ("src_f32", "ctx_f32", "tgt_f32"))
+    image = tf1.placeholder(tf.float32, (3,) + src.shape)
+    model = mod.ContextAEInception2([int(v) for v in z["strides"]], [int(v) for v in z["kernels"]], [int(v) for v in z["filters"]])
+    model.build(image)
+    tvars = {v.name[:-2]: v for v in tf1.trainable_variables()}
+    missing = sorted(set(p) - set(tvars)), sorted(set(tvars) - set(p))
+    assert missing == ([], []), f"variable names differ from the oracle's inventory: {missing}"
+    names = list(p)
+    lrph = tf1.placeholder(tf.float32, ())
+    grads = tf1.gradients(model.loss, [tvars[n] for n in names])
+    opt = tf1.train.AdamOptimizer(lrph).minimize(model.loss, var_list=[tvars[n] for n in names])
+    out = {}
+    with tf1.Session() as sess:
+        sess.run(tf1.global_variables_initializer())
+        for n in names:
+            sess.run(tvars[n].assign(np.asarray(p[n], np.float32)))
+        feed = {image: np.stack([src, ctx, tgt])}
+        fetch = dict(input_z=model.input_z, translated_z=model.translated_z, out=model.out, out2=model.out2, loss=model.loss,
+                     simloss=model.simloss, recon1=model.recon1, recon2=model.recon2)
+        res = sess.run(fetch, feed)
+        out.update({k: np.asarray(res[k], np.float32) for k in ("input_z", "translated_z", "out", "out2")})
+        out["scalars"] = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]], np.float64)
+        g = sess.run(grads, feed)
+        out["grad_digest"] = np.stack([digest(x)[0] for x in g])
+        out["grad_head"] = np.stack([np.pad(digest(x)[1], (0, N_HEAD - min(N_HEAD, x.size))) for x in g])
+        c0 = np.broadcast_to(ctx[0], src.shape)
+        tz, pred = sess.run([model.translated_z, model.out], {image: np.stack([src, c0, c0])})
+        out["translate_pred"], out["translate_feat"] = np.asarray(pred, np.float32), np.asarray(tz, np.float32)
+        out["encode_feat"] = out["input_z"]
+        traj = []
+        for _ in range(int(z["steps"])):
+            _, l, s_, r1, r2 = sess.run([opt, model.loss, model.simloss, model.recon1, model.recon2], {**feed, lrph: float(z["lr"])})
+            traj.append([l, s_, r1, r2])
+        out["train_scalars"] = np.array(traj, np.float64)
+    return out
+
+
+def run_reference_inception_v3(root, z):
+    """inception_v3.inception_v3(images, num_classes=1001, is_training=False)[1] (rllab/sampler/base.py:122-127;
+    nets/inception_v3.py:93-416) with the oracle's synthetic variables assigned BY NAME; returns the end points the fixture holds."""
+    import tensorflow as tf
+    tf1 = tf.compat.v1 if hasattr(tf, "compat") and hasattr(tf.compat, "v1") else tf
+    from oracle import inception_oracle as io
+    sys.path.insert(0, root)
+    from nets import inception_v3 as ref_net                      # the reference's own file, loaded from REFERENCE_ROOT
+    slim = tf.contrib.slim
+    tf1.reset_default_graph()
+    frames = z["frames_u8"]
+    u8 = tf1.placeholder(tf.uint8, frames.shape)
+    images = tf1.multiply(tf1.subtract(tf.image.convert_image_dtype(u8, dtype=tf.float32), 0.5), 2.0)     # base.py:116-119
+    with slim.arg_scope(ref_net.inception_v3_arg_scope()):
+        _, end_points = ref_net.inception_v3(images, num_classes=1001, is_training=False)
+    p = io.init_params(int(z["pseed"]), np.float32)
+    allv = {v.name[:-2]: v for v in tf1.global_variables()}
+    names = [str(n) for n in z["endpoints"]]
+    with tf1.Session() as sess:
+        sess.run(tf1.global_variables_initializer())
+        for n, a in p.items():
+            sess.run(allv["InceptionV3/" + n].assign(a))
+        got = sess.run([end_points[n] for n in names], {u8: frames})
+    ep = dict(zip(names, got))
+    return {"Mixed_7c": np.asarray(ep["Mixed_7c"], np.float32),
+            "endpoint_digest": np.stack([digest(v)[0] for v in got]),
+            "endpoint_head": np.stack([digest(v)[1] for v in got])}
+
+
 def fixture_inputs(path, real):
     z = np.load(path)
     if real:
@@ -130,6 +204,33 @@ def main():
         else:
             keep = {k: z[k] for k in ("cfg", "B", "pseed", "stddev", "src_u8", "ctx_u8", "tgt_u8", "lr", "steps", "param_digest")}
             np.savez_compressed(os.path.join(HERE, f"tf_{tag}.npz"), **keep, **got)
+            print("wrote", f"tf_{tag}.npz")
+    # ContextAEInception2 (strides / kernels / filters are constructor arguments) and the Inception-v3 front end
+    from oracle import ctx_oracle_incep as ci
+    extra = []
+    for tag in ("incep2_4x4x64_f32_b2", "incep2_8x4x32_k5331_s2121_b2"):
+        z = np.load(os.path.join(HERE, tag + ".npz"))
+        H, W, C, F = (int(v) for v in z["cfg"])
+        cfg = ci.Incep2Config(H=H, W=W, C=C, featsize=F, strides=tuple(int(v) for v in z["strides"]),
+                              kernels=tuple(int(v) for v in z["kernels"]), filters=tuple(int(v) for v in z["filters"]))
+        p = ci.init_params(cfg, int(z["pseed"]), np.float64, stddev=float(z["stddev"]))
+        brng = np.random.default_rng(int(z["pseed"]) + 1)
+        for n in p:
+            if n.endswith("bias") or n.endswith("biases"):
+                p[n] = brng.standard_normal(p[n].shape) * float(z["stddev"])
+        keep = ("cfg", "strides", "kernels", "filters", "B", "pseed", "stddev", "fseed", "lr", "steps", "param_digest")
+        extra.append((tag, z, run_reference_incep2(mod, z, p), keep))
+    z = np.load(os.path.join(HERE, "inception_v3_125x125_b2.npz"))
+    extra.append(("inception_v3_125x125_b2", z, run_reference_inception_v3(root, z), ("pseed", "fseed", "B", "S", "endpoints", "param_digest")))
+    for tag, z, got, keep in extra:
+        if args.check:
+            for k, v in got.items():
+                ref = np.asarray(z[k], np.float64)
+                dev = float(np.abs(np.asarray(v, np.float64) - ref).max() / (np.abs(ref).max() + 1e-30))
+                worst = max(worst, dev)
+                print(f"{tag:32s} {k:16s} max deviation / max |oracle| = {dev:.2e}")
+        else:
+            np.savez_compressed(os.path.join(HERE, f"tf_{tag}.npz"), **{k: z[k] for k in keep}, **got)
             print("wrote", f"tf_{tag}.npz")
     if args.check:
         print("worst deviation:", worst, "-> oracle", "PINNED (<= 1e-4)" if worst <= 1e-4 else "DIFFERS from the reference")

@@ -55,3 +55,37 @@ def test_oracle_f32_is_within_budget_of_golden_f64():
     res, _ = o.forward(p32, src, ctx, tgt, cfg)
     assert np.abs(res["out"] - z["out"]).max() <= 1e-4 * np.abs(z["out"]).max()
     assert abs(res["loss"] - z["scalars"][0]) <= 1e-5 * z["scalars"][0]
+
+
+# ---- the other model classes' fixtures (tests/golden/make_golden.py extra): guards against RNG / oracle drift; the TF recipe
+# (tests/golden/make_tf_fixtures.py) and tests/test_tf_pin.py read the same files
+@pytest.mark.parametrize("tag", ["incep2_4x4x64_f32_b2", "incep2_8x4x32_k5331_s2121_b2"])
+def test_incep2_oracle_reproduces_golden(tag):
+    from oracle import ctx_oracle_incep as ci
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", tag + ".npz"))
+    H, W, C, F = (int(v) for v in z["cfg"])
+    cfg = ci.Incep2Config(H=H, W=W, C=C, featsize=F, strides=tuple(int(v) for v in z["strides"]),
+                          kernels=tuple(int(v) for v in z["kernels"]), filters=tuple(int(v) for v in z["filters"]))
+    p = ci.init_params(cfg, int(z["pseed"]), np.float64, stddev=float(z["stddev"]))
+    brng = np.random.default_rng(int(z["pseed"]) + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * float(z["stddev"])
+    np.testing.assert_allclose(digest(ci.flatten(p, cfg)), z["param_digest"], rtol=1e-12)
+    src, ctx, tgt = (z[k].astype(np.float64) for k in ("src_f32", "ctx_f32", "tgt_f32"))
+    res, c = ci.forward(p, src, ctx, tgt, cfg)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        np.testing.assert_allclose(res[k], z[k], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose([res["loss"], res["simloss"], res["recon1"], res["recon2"]], z["scalars"], rtol=1e-12)
+    g = ci.backward(p, c, cfg)
+    for i, (n, _) in enumerate(ci.param_specs(cfg)):
+        np.testing.assert_allclose(digest(g[n]), z["grad_digest"][i], rtol=1e-9, atol=1e-12)
+
+
+def test_inception_oracle_reproduces_golden():
+    from oracle import inception_oracle as io
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "inception_v3_125x125_b2.npz"))
+    ep = io.forward(io.init_params(int(z["pseed"])), o.preprocess_u8(z["frames_u8"]).astype(np.float64))
+    assert list(ep) == [str(n) for n in z["endpoints"]]
+    np.testing.assert_allclose(ep["Mixed_7c"], z["Mixed_7c"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.stack([digest(v) for v in ep.values()]), z["endpoint_digest"], rtol=1e-9)

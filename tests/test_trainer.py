@@ -86,8 +86,13 @@ def reference_loop(vdata, seed, basedir):
             if itr % SAVE == 0:
                 test.saved.append("%s%d/model_%d_%.2f_%.2f_%.2f_%d" % (basedir, itr, itr, loss, r1, r2, err))
                 for kk in range(10):
-                    np.random.randint(nvalid)
-                    np.random.randint(nvalid)
+                    choicesrc = [np.random.randint(nvalid)] * batch_size
+                    choicetgt = [np.random.randint(nvalid)] * batch_size
+                    srcdata = validdata[np.arange(0, batch_size) % nlen, choicesrc]
+                    tgtdata = validdata[np.arange(0, batch_size) % nlen, choicetgt]
+                    tgtctx = validdata[0, choicetgt]
+                    clip = test.evaluate(srcdata, tgtctx, tgtdata)
+                    r1, r2 = clip["recon1"], clip["recon2"]          # (:192-193: the clip fetch re-uses the names r1, r2)
             if itr >= SAVE:
                 rows.append([itr, loss, sim, r1, r2, err])
     return test, lines, rows, validloss
@@ -162,7 +167,7 @@ def test_trainer_on_the_hip_translator_resident_and_host_paths_agree(tmp_path):
     Hh = Ww = 16
     rng = np.random.default_rng(1)
     base = rng.integers(0, 256, (1, 6, Hh, Ww, 3))                  # videos = a base frame drifting over time: learnable
-    u8 = np.clip(base + np.arange(4)[:, None, None, None, None] * 9, 0, 255).astype(np.uint8)
+    u8 = np.clip(base + np.arange(6)[:, None, None, None, None] * 9, 0, 255).astype(np.uint8)    # T = 6 frames > nlen = 4: only t < nlen may be sampled
     vdata = u8 / 127.5 - 1.0
     runs = {}
     for mode in ("resident", "host"):

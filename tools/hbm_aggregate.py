@@ -11,7 +11,10 @@ import sys
 def group(k):
     m = re.match(r"void ctx::igemm(_split)?_kernel<ctx::(\w+), ctx::(\w+),", k)
     if not m:
-        return "adam" if "adam_kernel" in k else k
+        if "adam_kernel" in k:
+            return "adam"
+        d = re.match(r"void ctx::(dconv_fwd_kernel|dconv_wgrad_kernel|convt3_kernel)<", k)     # the labels ctx_profile_step uses for the direct kernels
+        return d.group(1) if d else k
     a, b = m.group(2), m.group(3)
     if a.startswith("KmConvTGather"):
         return "igemm<ConvTGather,ConvTWeights>"
@@ -42,7 +45,10 @@ def main(d, prec, out):
                 acc[k][c] += float(r["Counter_Value"])
                 if c == "FETCH_SIZE":
                     n[k] += 1
-    res = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --steps 1 "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res = {"csrc_sha16": bench.csrc_sha16(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on python bench.py --steps 1 "
                      "--warmup 1 --kernel-iters 1, CTX_OVERLAP=0, B=256, precision " + prec + "; bytes = FETCH_SIZE*1024*2 "
                      "(gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE*1024", "per_kernel": {}}
     for k, v in acc.items():
