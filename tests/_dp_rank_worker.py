@@ -1,0 +1,76 @@
+"""One rank of tests/test_gpu_dp_two_ranks.py: a separate PROCESS that drives the C-ABI data-parallel path (ctx_dp_*) on its
+shard.  usage: python tests/_dp_rank_worker.py <rank> <world> <workdir>   (CTX_RCCL_LIB = the stand-in, set by the parent)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+H = W = 32
+D, F, SHARD, LR, PSEED = 32, 128, 8, 1e-3, 321
+
+
+def full_batch(world):
+    rng = np.random.default_rng(17)
+    return [rng.uniform(-1, 1, (SHARD * world, H, W, 3)).astype(np.float32) for _ in range(3)]     # src, ctx, tgt
+
+
+def main():
+    rank, world, work = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    import torch   # owner of the device buffers the shard lives in (plumbing)
+    from imitation_from_observation_amd import Translator
+    from oracle import ctx_oracle as o   # parameter initialiser only (so that the parent's oracle holds the same parameters)
+    cfg = o.SkipNewConfig(H=H, W=W, df_dim=D, gf_dim=D, featsize=F)
+    # rank 0 holds the parameters the parent's oracle uses; the other ranks start from DIFFERENT ones and a different Adam
+    # step counter: ctx_dp_init must make every replica rank 0's
+    p = o.init_params(cfg, PSEED + rank, np.float32, stddev=0.05)
+    tr = Translator(H, W, D, F, max_batch=SHARD)
+    tr.set_params(p)
+    if rank:
+        n = tr.n_params
+        tr.set_adam_state(np.full(n, 0.5, np.float32), np.full(n, 0.25, np.float32), 7)
+    idfile = os.path.join(work, "uid.bin")
+    if rank == 0:
+        uid = Translator.dp_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 60:
+                raise SystemExit("rank 0 never published the unique id")
+            time.sleep(0.01)
+        uid = open(idfile, "rb").read()
+    tr.dp_init(uid, rank, world)
+    out = {"params0": tr.get_params_flat(), "adam_step0": np.int64(tr.get_adam_state()[2])}
+    sl = slice(rank * SHARD, (rank + 1) * SHARD)
+    dev = [torch.from_numpy(np.ascontiguousarray(x[sl])).cuda() for x in full_batch(world)]
+    torch.cuda.synchronize()
+    ptr = [t.data_ptr() for t in dev]
+    # (a) the exchange step alone between the phases: forward/backward with the GLOBAL simloss denominator -> all-reduce
+    tr.dev_forward_backward(ptr[0], ptr[1], ptr[2], SHARD, sim_batch=SHARD * world)
+    tr.dp_allreduce_grads()
+    tr.sync()
+    out["grads_phases"] = tr.get_grads_flat()
+    out["scalars_phases"] = np.array(list(tr.dp_scalars().values()), np.float64)
+    # (b) the whole step: two buckets, second stream, Adam -- three times
+    for k in range(3):
+        sc = tr.dp_train_step(ptr[0], ptr[1], ptr[2], SHARD, lr=LR, scalars=True)
+        out[f"scalars{k + 1}"] = np.array([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]], np.float64)
+        if k == 0:
+            tr.sync()
+            out["grads1"] = tr.get_grads_flat()
+    tr.sync()
+    out["params3"] = tr.get_params_flat()
+    out["adam_step3"] = np.int64(tr.get_adam_state()[2])
+    np.savez(os.path.join(work, f"rank{rank}.npz"), **out)
+    tr.close()
+    print(f"rank {rank} ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""The C-ABI data-parallel path (ctx_dp_unique_id / ctx_dp_init / ctx_dp_allreduce_grads / ctx_dp_train_step / ctx_dp_scalars,
+include/ctxtrans.h) executed by TWO PROCESSES.  The gpurun boxes have one GPU and real RCCL will not put two ranks on one
+device, so the collectives go through tests/fake_rccl (a shared-memory stand-in loaded via CTX_RCCL_LIB: asynchronous,
+stream-ordered, fixed rank-order sums); everything else -- the two-bucket schedule, the second stream, the events, the global
+simloss denominator, Adam behind the reduced gradients -- is the shipped code.  The three claims of tests/test_dp_gloo.py,
+now for this path: summed shard gradients = full-batch gradient (float64 oracle, B = 2 x 8), replicas bit-identical after 3
+steps, global scalars right.  Reference: none (the reference is single-device)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import ctx_oracle as o
+from tests import _dp_rank_worker as wk
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FAKE = os.path.join(HERE, "fake_rccl", "libfakerccl.so")
+
+
+def test_fake_rccl_exports_what_libctxtrans_binds():
+    """CPU: the stand-in is built (by __graft_entry__.build()) and exports the eight symbols rccl_load() looks up."""
+    import ctypes
+    if not os.path.exists(FAKE):
+        subprocess.run(["make", "-C", os.path.dirname(FAKE)], check=True)
+    lib = ctypes.CDLL(FAKE)
+    for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclBroadcast", "ncclGroupStart",
+              "ncclGroupEnd", "ncclGetErrorString"):
+        assert hasattr(lib, s), s
+
+
+@pytest.mark.gpu
+def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    assert os.path.exists(FAKE), "tests/fake_rccl/libfakerccl.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    world = 2
+    env = dict(os.environ, CTX_RCCL_LIB=FAKE)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_dp_rank_worker.py"), str(r), str(world), str(tmp_path)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    try:
+        for pr in procs:
+            logs.append(pr.communicate(timeout=300)[0])
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    for r, pr in enumerate(procs):
+        assert pr.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    z = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+
+    # ---- ctx_dp_init: every replica starts as rank 0 (parameters, Adam slots' effect, step counter)
+    np.testing.assert_array_equal(z[0]["params0"], z[1]["params0"])
+    assert int(z[0]["adam_step0"]) == int(z[1]["adam_step0"]) == 0
+
+    # ---- the oracle on the FULL batch with rank 0's parameters
+    cfg = o.SkipNewConfig(H=wk.H, W=wk.W, df_dim=wk.D, gf_dim=wk.D, featsize=wk.F)
+    p = {k: v.astype(np.float64) for k, v in o.init_params(cfg, wk.PSEED, np.float32, stddev=0.05).items()}
+    np.testing.assert_array_equal(o.flatten(p, cfg).astype(np.float32), z[0]["params0"])
+    src, ctx, tgt = (x.astype(np.float64) for x in wk.full_batch(world))
+    res, c = o.forward(p, src, ctx, tgt, cfg)
+    g = o.flatten(o.backward(p, c, cfg), cfg)
+    want = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]])
+
+    # ---- claim 1: summed shard gradients = full-batch gradient; the bucketed step and the plain exchange agree bit for bit
+    for r in range(world):
+        np.testing.assert_array_equal(z[r]["grads_phases"], z[r]["grads1"])
+    np.testing.assert_array_equal(z[0]["grads1"], z[1]["grads1"])
+    off = 0
+    for name, shape in o.param_specs(cfg):
+        n = int(np.prod(shape))
+        a, b = z[0]["grads1"][off:off + n].astype(np.float64), g[off:off + n]
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 1e-12, (name, np.abs(a - b).max() / np.abs(b).max())
+        off += n
+    # ---- claim 3: global scalars (sum of recon sums, mean of simloss means)
+    for key in ("scalars_phases", "scalars1"):
+        np.testing.assert_allclose(z[0][key], want, rtol=2e-5)
+        np.testing.assert_array_equal(z[0][key], z[1][key])
+    # ---- claim 2: replicas bit-identical after three steps, and on the oracle's Adam trajectory
+    np.testing.assert_array_equal(z[0]["params3"], z[1]["params3"])
+    assert int(z[0]["adam_step3"]) == int(z[1]["adam_step3"]) == 3
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    traj = []
+    for t in range(1, 4):
+        r_, _ = o.train_step(p, m, v, t, src, ctx, tgt, wk.LR, cfg)
+        traj.append([r_["loss"], r_["simloss"], r_["recon1"], r_["recon2"]])
+    for k in range(3):
+        np.testing.assert_allclose(z[0][f"scalars{k + 1}"], traj[k], rtol=1e-4)
+    assert traj[2][0] < traj[0][0]                                                  # the steps moved the loss
+    delta = z[0]["params3"].astype(np.float64) - z[0]["params0"]
+    want_delta = o.flatten(p, cfg) - z[0]["params0"]
+    assert np.abs(delta - want_delta).max() <= 2e-2 * np.abs(want_delta).max()      # Adam's first steps are ~ +-lr: sign-sensitive entries
+    assert np.corrcoef(delta, want_delta)[0, 1] > 0.999
