@@ -425,6 +425,7 @@ const char* const K_CONVT3P = "igemm<Cat2,KmPlain>";
 const char* const K_CONVT3D = "convt3_kernel";
 // the narrow-channel direct kernels of dconv.h (ContextSkipNew's 3-channel edge layers in f32, all of ContextAEReal's narrow path):
 // a launch group is labelled with the kernel that actually runs it
+const char* const K_WCONVT = "wconvt_kernel";       // wide-channel transposed conv with the input halo tile in LDS (wconvt.hip)
 const char* const K_DCFWD = "dconv_fwd_kernel";
 const char* const K_DCWGRAD = "dconv_wgrad_kernel";
 const char* const K_COLSUM = "colsum";
@@ -593,10 +594,12 @@ void forward(ctx_handle* h, int B, Mode mode) {
         const double fl = 2.0 * nd * hs * ws * 25 * (c1 + c2) * ca;
         if (k < 4) {
             const int R = nd * hs * ws;
-            ProfScope ps(h, nm_ + " fwd", K_CONVT, fl);
+            const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, ws, c1, c2, ca);
+            ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
+            if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, B, nd, hs, ws, w, ca, ep);
+            else if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
                                        KmConvTWeightsQ{w, ca, c1 + c2, 5, g_zeros}, ep, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
                            KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
@@ -762,8 +765,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add1 = h->dSk[k - 1]; ed.lda1 = ca;
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
-            ProfScope ps(h, ln + " dx", K_CONVT, fl);
-            if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
+            const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, wsm, cb, 0, ca);
+            ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl);
+            if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed);
+            else if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
                                          KmConvTWeightsQ{sc.w[k], ca, cb, 5, g_zeros}, ed, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},
                            ed, R, ca, ws_of(h));

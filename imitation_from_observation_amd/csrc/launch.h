@@ -52,6 +52,12 @@ void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_t
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   // filter gradient of either, 25 taps in one launch
 
+// conv2d_transpose 5x5 stride 2 for wide channel counts on the 8x8 / 16x16 grids: image-major, input halo tile resident in LDS
+// (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
+bool wconvt_ok(int hs, int ws, int c1, int c2, int ca);
+void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
+                const Epi& ep);
+
 // conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
 // product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a
 // gather of the <= 9 taps that land on each output pixel (deterministic, no atomics).

@@ -1,0 +1,313 @@
+// wconvt.hip -- conv2d_transpose 5x5 stride 2 (arm_shaping.py:62-85) for WIDE channel counts (cin, cout multiples of 32) on the
+// 8x8 and 16x16 grids, image-major with the input HALO TILE resident in LDS.  Round 3.
+//
+// Why: the position-major implicit GEMM (igemm.h: KmConvTGatherQ) streams BOTH operands of every 128x128x32 chunk from L2 --
+// 21-32 FLOP per byte fed to LDS, the measured "real streaming loads" ceiling of DESIGN.md section 6 -- and re-fetches every
+// input pixel once per (tap, parity class) it serves (up to 25 times; 779 MB through the fabric per launch for ~125 MB of
+// tensors).  Here a block owns IMG whole images (256 output positions per parity class) and a 32*NB-wide slice of output
+// channels for ALL FOUR parity classes:
+//   * a 32-channel slice of the images' input pixels (+ a one-pixel zero halo) is staged in LDS ONCE and serves all 25 taps:
+//     6400*NB/2 MFMAs per 47-58 KB staged, against 128 MFMAs per 24.5 KB before;
+//   * the filter goes through a two-stage LDS ring, one (tap, slice) = 32*NB x 32 floats at a time (one float4 per thread), one
+//     barrier per tap = per 32*NB/2... MFMAs of every wave;
+//   * wave w owns rows [32 w, 32 w + 32) of the 256 and keeps 4 classes x NB accumulators (128 registers at NB = 2); the tap ->
+//     (class, pixel shift) table is compile time, so a tap's A fragment is one ds_read_b128 at a literal offset from the lane's
+//     base address, and the loop has no address arithmetic at all.
+// All 25 taps are formed for every pixel (the halo holds zeros): 14 % / 7 % of the products on 8x8 / 16x16 grids meet a zero;
+// the 4x4 layers (28 %) stay on the class-major implicit GEMM.
+// v_mfma_f32_32x32x2_f32, exact f32.  k order inside a slice: step (q, t): lanes 0-31 take channel 8q + t, lanes 32-63 8q + 4 + t
+// (both operands alike).  LDS: A [halo pixel][36], B [2][32 NB][36] floats -- ds_read_b128 at a 36-dword row stride is conflict free.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#include "launch.h"
+
+namespace ctx {
+
+namespace {
+
+constexpr int WC_THREADS = 256;                 // 4 waves, one per SIMD; two blocks share a CU (LDS 44-47 KB, <= 256 registers)
+constexpr int WC_ROWS = 128;                    // output positions (per parity class) of a block
+constexpr int WC_LDP = 36;                      // floats per LDS row (32 channels + 4 pad)
+
+struct WcT {
+    const float* s1; int c1;                     // input [nimg, HS, WS, c1]
+    const float* s2; int c2; int nmod2;          // second channel group [nmod2, HS, WS, c2] (ctx skip, image n % nmod2), c2 = 0: none
+    const float* w; int ca;                      // filter [5][5][ca][c1 + c2], ca = output channels
+    int nimg;
+    int gn;                                      // column tiles
+    Epi ep;
+};
+
+// tap t of the 25 in class order (0,0) x4, (0,1) x6, (1,0) x6, (1,1) x9.  Class (py, px): taps ky = par + 2 sy with par = (py + 1) & 1,
+// input row i + oy - sy, oy = (py + 1 - par) / 2 (KmConvTGather's notation, K = 5, pb = 1).
+struct TapInfo { int cls, dy, dx, ky, kx; };
+__host__ __device__ constexpr TapInfo tap_info(int t) {
+    const int c = t < 4 ? 0 : t < 10 ? 1 : t < 16 ? 2 : 3;
+    const int u = t - (c == 0 ? 0 : c == 1 ? 4 : c == 2 ? 10 : 16);
+    const int py = c >> 1, px = c & 1;
+    const int pary = (py + 1) & 1, parx = (px + 1) & 1;
+    const int ntx = (5 - parx + 1) >> 1;
+    const int sy = u / ntx, sx = u - sy * ntx;
+    const int oy = (py + 1 - pary) >> 1, ox = (px + 1 - parx) >> 1;
+    return TapInfo{c, oy - sy, ox - sx, pary + 2 * sy, parx + 2 * sx};
+}
+
+// MFMA row (= lane & 31 for the A operand) -> position index inside the wave's 32 positions (row-major over grid rows of WS).
+// The 16 lanes of a ds_read_b128 group must hit 16 pixel slots that are distinct mod 16:
+//   WS = 16: group A lanes {0-3,12-15,20-27} take grid row 0 (columns in lane order), group B lanes {4-11,16-19,28-31} row 1;
+//   WS = 8 (pitch 12): group A takes rows 0 and 2 (slots 0-7 and 24-31 = 8-15 mod 16), group B rows 1 and 3 (12-19, 36-43);
+//   WS = 4: positions in lane order (the 4x4 instance is not tuned).
+template <int WS>
+__device__ __forceinline__ int wc_pos(int row) {
+    if constexpr (WS == 4) return row;
+    // k = index of the lane inside its group, in the order the hardware lists the group
+    const bool ga = row < 4 || (row >= 12 && row < 16) || (row >= 20 && row < 28);
+    const int k = ga ? (row < 4 ? row : row < 16 ? row - 8 : row - 12) : (row < 12 ? row - 4 : row < 20 ? row - 8 : row - 16);
+    if constexpr (WS == 16) return (ga ? 0 : 16) + k;                      // one grid row per group
+    else return ((ga ? 0 : 1) + (k >> 3) * 2) * 8 + (k & 7);               // WS = 8: rows {0, 2} / {1, 3}
+}
+
+// A block = TH grid rows of IMGT images (TH * WS * IMGT = 128 positions) x 32 NB output channels x the four parity classes.
+//   16x16 grid: half an image (TH = 8, halo tile 10 x 18);   8x8 grid: two images (halo tile 2 x 10 x 10)
+template <int HS, int WS, int NB>
+__global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
+    constexpr int TH = HS * WS >= WC_ROWS ? WC_ROWS / WS : HS, IMGT = WC_ROWS / (TH * WS), TPI = HS / TH;   // rows per tile, images per tile, tiles per image
+    // halo tile in LDS: HP rows of WPL pixel slots per image (WP = WS + 2 of them used).  ds_read_b128 serves a wave in four groups of 16
+    // lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32); a group is conflict free when its 16 pixel slots are distinct
+    // mod 16 (36-dword slots: 9 sixteen-byte units each, 9 is odd).  16-wide grids: a group = one grid row (any pitch).  8-wide grids:
+    // a group = two rows two apart, which needs the pitch = 12 slots (10 would put three rows on slot 0 mod 16); PMC before: 38 % of
+    // the LDS cycles of the 8x8 launches were bank conflicts.  `wc_pos` is the lane -> position map that goes with it.
+    constexpr int HP = TH + 2, WP = WS + 2, WPL = WS == 8 ? 12 : WP, TPIX = IMGT * HP * WPL;
+    constexpr int NPA = (TPIX * 8 + WC_THREADS - 1) / WC_THREADS;        // float4 per thread per A slice
+    constexpr int BROWS = 32 * NB, BSTAGE = BROWS * WC_LDP;              // floats per B stage
+    constexpr int NPB = BROWS * 8 / WC_THREADS;                          // float4 per thread per filter tile (1 or 2)
+    static_assert(NPB >= 1 && TH * WS * IMGT == WC_ROWS, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + TPIX * WC_LDP;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    // block -> (tile, column tile): the column tiles of one tile sit on ONE XCD (blocks are dealt round-robin to the 8 XCDs), next to
+    // each other in dispatch order, so that the second one finds the input pixels in that XCD's L2
+    int item = blockIdx.x;
+    {
+        const int xcd = item & 7, l = item >> 3, nt = l % P.gn, g8 = l / P.gn;
+        item = (g8 * 8 + xcd) * P.gn + nt;
+    }
+    const int ntile = ((P.nimg + IMGT - 1) / IMGT) * TPI;
+    const int tile = item / P.gn, ctile = item - tile * P.gn;
+    if (tile >= ntile) return;
+    const int img0 = (tile / TPI) * IMGT, i0 = (tile % TPI) * TH, n0 = ctile * BROWS;
+    const int cb = P.c1 + P.c2, nslice = cb >> 5, ns1 = P.c1 >> 5;
+
+    const rsrc_t rs1 = make_rsrc(P.s1), rs2 = make_rsrc(P.s2 ? P.s2 : P.s1);
+
+    // ---- loaders -----------------------------------------------------------------------------------------------
+    // A: float4 f = tid + 256 p of the slice tile: halo pixel f >> 3 (tile-local (il, y, x)), channels 4 (f & 7) ..
+    auto a_load = [&](int slice, int p) -> float4 {
+        const int f = tid + WC_THREADS * p;
+        const int hp = f >> 3, k4 = (f & 7) * 4;
+        const int il = hp / (HP * WPL), r = hp - il * (HP * WPL), y = i0 + r / WPL - 1, x = r - (r / WPL) * WPL - 1;   // (slots x >= WS + 1 are padding: zeros)
+        const int img = img0 + il;
+        const bool ok = f < TPIX * 8 && (unsigned)y < (unsigned)HS && (unsigned)x < (unsigned)WS && img < P.nimg;
+        const bool second = slice >= ns1;
+        const int im = second ? img % P.nmod2 : img;
+        const int ld = second ? P.c2 : P.c1, kc = (second ? slice - ns1 : slice) * 32;
+        const uint32_t v = (uint32_t)(((im * HS + y) * WS + x) * ld + kc + k4) * 4u;
+        return bload4(second ? rs2 : rs1, ok ? v : OOB);
+    };
+    auto a_store = [&](int p, float4 v) {
+        const int f = tid + WC_THREADS * p;
+        if (f < TPIX * 8) *reinterpret_cast<float4*>(&sA[(f >> 3) * WC_LDP + (f & 7) * 4]) = v;
+    };
+    // B: (tap, slice) tile = rows n0 .. n0 + 32 NB of w[ky][kx][.][slice * 32 ..]: float4 (tid + 256 p) -> row >> 3, channels 4 (. & 7)
+    const int bk4 = (tid & 7) * 4;
+    uint32_t bvoff[NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        const int row = (tid >> 3) + 32 * p;
+        bvoff[p] = n0 + row < P.ca ? (uint32_t)((n0 + row) * cb + bk4) * 4u : OOB;
+    }
+    auto b_load = [&](int slice, int tapw, float4 (&v)[NPB]) {         // tapw = ky * 5 + kx: a literal at every call site
+        if (slice >= nslice) slice = nslice - 1;                       // (redundant tail reloads are harmless)
+        const rsrc_t r = make_rsrc(P.w + ((int64_t)tapw * P.ca) * cb + slice * 32);
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) v[p] = bload4(r, bvoff[p]);
+    };
+    auto b_store = [&](int stage, const float4 (&v)[NPB]) {
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) *reinterpret_cast<float4*>(&sB[stage * BSTAGE + ((tid >> 3) + 32 * p) * WC_LDP + bk4]) = v[p];
+    };
+
+    // ---- fragment addresses ------------------------------------------------------------------------------------
+    // row m = 32 wv + l31 of the 128: tile-local position; the lane's base = halo pixel (i, j) = input pixel (i - 1, j - 1), so that
+    // tap shift (dy, dx) in {-1, 0, 1}^2 is the non-negative literal offset ((dy + 1) WP + dx + 1) rows
+    const int m = 32 * wv + wc_pos<WS>(l31), il = m / (TH * WS), pp = m - il * (TH * WS), pi = pp / WS, pj = pp - pi * WS;
+    const float* aBase = sA + ((il * HP + pi) * WPL + pj) * WC_LDP + 4 * h;
+    const float* bBase = sB + l31 * WC_LDP + 4 * h;
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][nb][r] = 0.f;
+
+    // ---- prologue: slice 0 and tap 0 into LDS, tap 1 into the registers ------------------------------------------
+    float4 areg[NPA], breg[NPB];
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) areg[p] = a_load(0, p);
+    b_load(0, tap_info(0).ky * 5 + tap_info(0).kx, breg);
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) a_store(p, areg[p]);
+    b_store(0, breg);
+    b_load(0, tap_info(1).ky * 5 + tap_info(1).kx, breg);
+    __syncthreads();
+
+    for (int s = 0; s < nslice; ++s) {
+        const int snext = s + 1 < nslice ? s + 1 : s;
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const TapInfo ti = tap_info(t);
+            const int g = s * 25 + t;
+            const int stage = g & 1;
+            const float* aT = aBase + ((ti.dy + 1) * WPL + (ti.dx + 1)) * WC_LDP;
+            const float* bT = bBase + stage * BSTAGE;
+            float4 a[2], b[2][NB];
+            a[0] = *reinterpret_cast<const float4*>(aT);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) b[0][nb] = *reinterpret_cast<const float4*>(bT + nb * 32 * WC_LDP);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+                    a[(q + 1) & 1] = *reinterpret_cast<const float4*>(aT + 8 * (q + 1));
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) b[(q + 1) & 1][nb] = *reinterpret_cast<const float4*>(bT + nb * 32 * WC_LDP + 8 * (q + 1));
+                }
+                const float av[4] = {a[q & 1].x, a[q & 1].y, a[q & 1].z, a[q & 1].w};
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float4 bq = b[q & 1][nb];
+                        const float bv = tt == 0 ? bq.x : tt == 1 ? bq.y : tt == 2 ? bq.z : bq.w;
+                        // (filter value as the MFMA's row operand: D rows = output channels, columns = positions, so that a lane ends
+                        // up with 4 CONSECUTIVE CHANNELS of one position in 4 consecutive registers -- float4 epilogue)
+                        acc[ti.cls][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av[tt], acc[ti.cls][nb], 0, 0, 0);
+                    }
+                // in the gaps: the filter tile of tap g + 1 goes to the other stage, the one of tap g + 2 is requested, and the next
+                // slice's input pixels are requested one float4 per tap (they sit in registers until the slice ends)
+                if (q == 0) b_store(stage ^ 1, breg);
+                if (q == 1) {
+                    const int t2 = t + 2 < 25 ? t + 2 : t + 2 - 25;
+                    const TapInfo tj = tap_info(t2);
+                    b_load(t + 2 < 25 ? s : s + 1, tj.ky * 5 + tj.kx, breg);
+                }
+                if (q == 2 && t < NPA) areg[t] = a_load(snext, t);
+            }
+            __syncthreads();
+        }
+        if (s + 1 < nslice) {                     // every wave has finished with this slice's pixels (the barrier above)
+#pragma unroll
+            for (int p = 0; p < NPA; ++p) a_store(p, areg[p]);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue.  D = W x In^T: column = l31 = the lane's position, row = (r & 3) + 8 (r >> 2) + 4 h = output channel inside the
+    // 32-wide column block, i.e. registers 4g .. 4g + 3 are channels 8g + 4h .. + 3: every access below is one float4 per lane.  The
+    // tensors an element needs besides its own value (bias; skip gradients and the saved activation behind lrelu' on the
+    // input-gradient path) are loaded for a whole class first and only then applied (a per-element load -> wait -> store chain
+    // costs more than a slice of the MFMA loop).
+    const Epi& e = P.ep;
+    const int mm = 32 * wv + wc_pos<WS>(l31);
+    const int il2 = mm / (TH * WS), p2 = mm - il2 * (TH * WS), i2 = i0 + p2 / WS, j2 = p2 % WS;
+    const int img = img0 + il2;
+    const bool rowok = img < P.nimg;
+    const rsrc_t rm = make_rsrc(e.mask ? e.mask : P.s1), r1 = make_rsrc(e.add1 ? e.add1 : P.s1), r2 = make_rsrc(e.add2 ? e.add2 : P.s1);
+    const float leak = e.lrelu == 2 ? 0.f : LEAK;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const uint32_t pix = (uint32_t)((img * (2 * HS) + 2 * i2 + py) * (2 * WS) + 2 * j2 + px);       // < 2^29: one tensor is < 2 GiB
+        const uint32_t pa = (e.add1_mod && (int64_t)pix >= e.add1_mod) ? pix - (uint32_t)e.add1_mod : pix;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int nn = n0 + nb * 32 + 4 * h;
+            float4 bias[4], mk[4], a1[4], a2[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias[g] = e.bias ? ldg4(e.bias + nn + 8 * g) : zero4();
+            // (uniform branches: a launch either has these tensors or not)
+            if (e.mask) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) mk[g] = bload4(rm, rowok ? (pix * (uint32_t)e.ldm + nn + 8 * g) * 4u : OOB);
+            }
+            if (e.add1) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a1[g] = bload4(r1, rowok ? (pa * (uint32_t)e.lda1 + nn + 8 * g) * 4u : OOB);
+            }
+            if (e.add2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a2[g] = bload4(r2, rowok ? (pix * (uint32_t)e.lda2 + nn + 8 * g) * 4u : OOB);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[c][nb][4 * g], acc[c][nb][4 * g + 1], acc[c][nb][4 * g + 2], acc[c][nb][4 * g + 3]};
+                const float bb[4] = {bias[g].x, bias[g].y, bias[g].z, bias[g].w};
+                const float m4[4] = {mk[g].x, mk[g].y, mk[g].z, mk[g].w};
+                const float x1[4] = {a1[g].x, a1[g].y, a1[g].z, a1[g].w};
+                const float x2[4] = {a2[g].x, a2[g].y, a2[g].z, a2[g].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[u] += bb[u];
+                    if (e.add1) v[u] += x1[u];
+                    if (e.add2) v[u] += x2[u];
+                    if (e.lrelu) v[u] = fmaxf(v[u], leak * v[u]);
+                    if (e.mask) v[u] *= m4[u] >= 0.f ? 1.f : LEAK;
+                }
+                if (rowok) *reinterpret_cast<float4*>(e.out1 + (int64_t)pix * e.ld1 + nn + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <int HS, int WS, int NB>
+void launch_wc(hipStream_t s, const WcT& P) {
+    constexpr int TH = HS * WS >= WC_ROWS ? WC_ROWS / WS : HS, IMGT = WC_ROWS / (TH * WS), TPI = HS / TH;
+    constexpr int TPIX = IMGT * (TH + 2) * (WS == 8 ? 12 : WS + 2);
+    constexpr size_t lds = (size_t)(TPIX * WC_LDP + 2 * 32 * NB * WC_LDP) * sizeof(float);
+    static_assert(lds <= 65536, "two blocks per CU");
+    const int ntile = ((P.nimg + IMGT - 1) / IMGT) * TPI;
+    const int items = (ntile + 7) / 8 * 8 * P.gn;         // whole groups of 8 tiles: the XCD mapping above
+    hipLaunchKernelGGL((wconvt_kernel<HS, WS, NB>), dim3((unsigned)items), dim3(WC_THREADS), lds, s, P);
+}
+
+}  // namespace
+
+// the shapes this kernel is instantiated for (everything else stays on the implicit GEMM)
+bool wconvt_ok(int hs, int ws, int c1, int c2, int ca) {
+    static const bool on = [] { const char* e = getenv("CTX_WCONVT"); return !(e && e[0] == '0'); }();
+    // 4x4 grids: measured equal to the class-major implicit GEMM (d_h1 fwd 0.82 ms either way: 64 tiles x 4 column tiles leave one
+    // block per CU) -- kept behind CTX_WCONVT_4X4=1
+    static const bool on4 = [] { const char* e = getenv("CTX_WCONVT_4X4"); return e && e[0] == '1'; }();
+    return on && ((hs == 4 && ws == 4 && on4) || (hs == 8 && ws == 8) || (hs == 16 && ws == 16)) && c1 > 0 && c1 % 32 == 0 && c2 % 32 == 0 && ca % 32 == 0;
+}
+
+void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
+                const Epi& ep) {
+    WcT P{s1, c1, s2, c2, nmod2 > 0 ? nmod2 : 1, w, ca, nimg, 1, ep};
+    // 64 output channels per block where the launch still fills the chip's 512 block slots with them; 32 otherwise (small batches, ca = 32)
+    const int img_per = hs * ws >= 128 ? 1 : 128 / (hs * ws), tpi = hs * ws >= 128 ? hs * ws / 128 : 1;
+    const int64_t ntile = (int64_t)((nimg + img_per - 1) / img_per) * tpi;
+    static const int force_nb = [] { const char* e = getenv("CTX_WCONVT_NB"); return e ? atoi(e) : 0; }();     // A/B switch
+    const bool nb2 = ca % 64 == 0 && (force_nb ? force_nb == 2 : ntile * (ca / 64) >= 400);
+    P.gn = nb2 ? ca / 64 : ca / 32;
+    if (hs == 4) { if (nb2) launch_wc<4, 4, 2>(s, P); else launch_wc<4, 4, 1>(s, P); }
+    else if (hs == 8) { if (nb2) launch_wc<8, 8, 2>(s, P); else launch_wc<8, 8, 1>(s, P); }
+    else { if (nb2) launch_wc<16, 16, 2>(s, P); else launch_wc<16, 16, 1>(s, P); }
+}
+
+}  // namespace ctx
