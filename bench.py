@@ -361,7 +361,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from imitation_from_observation_amd.dp import DataParallelTrainer
+    from imitation_from_observation_amd.dp import DataParallelTrainer, RcclTrainer
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -383,7 +383,20 @@ def main():
         ctypes.CDLL(None).fflush(None)
 
     B = args.batch
-    trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision=args.precision)
+    # N > 1: the data-parallel step behind the C ABI (ctx_dp_train_step: RCCL inside libctxtrans, two gradient buckets, the tail
+    # bucket reduced on a second stream under the encoders' backward) -- torch.distributed only ships the 128-byte rendezvous blob
+    # and does the contract's barrier / max-over-ranks.  BENCH_DP=torch selects the torch.distributed client of the same step
+    # (dp.DataParallelTrainer: one all-reduce after backward, or the bucketed schedule with CTX_DP_OVERLAP=1).
+    dp_client = os.environ.get("BENCH_DP", "cabi") if dist.is_initialized() else "single"
+    if dp_client == "cabi":
+        trainer = RcclTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, rank=rank, world=world, precision=args.precision)
+    else:
+        trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision=args.precision)
+
+    def stream_of(tr_):
+        """torch view of the stream the step's kernels are enqueued on (for the HIP events)"""
+        eng = getattr(tr_, "engine", None)
+        return eng.stream if eng is not None else torch.cuda.ExternalStream(tr_.translator.stream_ptr)
     g = torch.Generator(device="cuda").manual_seed(100 + rank)
     frames = [torch.randint(0, 256, (B, H, W, 3), device="cuda", generator=g, dtype=torch.uint8) for _ in range(3)]
     src, ctx, tgt = (f.float() / 127.5 - 1.0 for f in frames)      # synthetic frames, train_script.py:16-19 scaling
@@ -398,7 +411,7 @@ def main():
             tr_.step(src, ctx, tgt, lr=1e-4)
         # HIP events on the stream the kernels are launched on, one per step boundary: median / min step time beside the
         # wall-clock mean that `value` is computed from
-        stream = tr_.engine.stream
+        stream = stream_of(tr_)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         barrier()
         t0 = time.perf_counter()
@@ -446,7 +459,10 @@ def main():
                    "precision": ("exact f32 MFMA" if args.precision == "f32" else
                                  "split-bf16: a*b = hi*hi + hi*lo + lo*hi on bf16 MFMA, f32 accumulate; f32 everywhere else"),
                    "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
-                   "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
+                   "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else ""),
+                   "dp_client": {"cabi": "ctx_dp_train_step (RCCL behind the C ABI, two buckets, second stream)",
+                                 "torch": "torch.distributed all-reduce between ctx_dev_forward_backward and ctx_dev_adam",
+                                 "single": "none (one rank)"}[dp_client]},
         "loss_after": scal["loss"],
         "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
         "step_ms_hip_events": step_events,          # rank 0's stream; `ms_per_step` / `value` are the wall-clock mean, max over ranks
@@ -466,32 +482,51 @@ def main():
         # per-N values can be read (exposed communication = ms_per_step - compute_ms; an overlapped schedule can hide at most
         # min(allreduce_ms, backward time)).  Every rank runs it; rank 0 reports its own clock.
         try:
-            eng = trainer.engine
             nrep = 5
-            with torch.cuda.stream(eng.stream):
-                eng.forward_backward(src, ctx, tgt, sim_batch=B * world)
-                eng.adam(1e-4)
-            barrier()
+            trl = trainer.translator
+            ptr = (src.data_ptr(), ctx.data_ptr(), tgt.data_ptr())
+            eng = getattr(trainer, "engine", None)
+            est = stream_of(trainer)
+
+            def compute_only():
+                if eng is not None:
+                    with torch.cuda.stream(est):
+                        eng.forward_backward(src, ctx, tgt, sim_batch=B * world)
+                        eng.adam(1e-4)
+                else:
+                    trl.dev_forward_backward(*ptr, B, sim_batch=B * world)
+                    trl.dev_adam(1e-4)
+
+            def allreduce_only():
+                if eng is not None:
+                    with torch.cuda.stream(est):
+                        dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
+                else:
+                    trl.dp_allreduce_grads()
+
+            def drain():
+                if eng is None:
+                    trl.sync()
+                barrier()
+
+            compute_only()
+            drain()
             t0 = time.perf_counter()
-            with torch.cuda.stream(eng.stream):
-                for _ in range(nrep):
-                    eng.forward_backward(src, ctx, tgt, sim_batch=B * world)
-                    eng.adam(1e-4)
-            barrier()
+            for _ in range(nrep):
+                compute_only()
+            drain()
             compute_ms = 1e3 * (time.perf_counter() - t0) / nrep
-            with torch.cuda.stream(eng.stream):
-                dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-            barrier()
+            allreduce_only()
+            drain()
             t0 = time.perf_counter()
-            with torch.cuda.stream(eng.stream):
-                for _ in range(nrep):
-                    dist.all_reduce(eng.grads, op=dist.ReduceOp.SUM)
-            barrier()
+            for _ in range(nrep):
+                allreduce_only()
+            drain()
             ar_ms = 1e3 * (time.perf_counter() - t0) / nrep
-            nbytes = eng.grads.numel() * 4
+            nbytes = trl.n_params * 4
             line["comm"] = {"payload_MB": nbytes / 1e6, "allreduce_ms": ar_ms, "compute_ms_per_step": compute_ms,
                             "busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if world > 1 else None,
-                            "overlap": os.environ.get("CTX_DP_OVERLAP", "0") == "1"}
+                            "client": dp_client, "overlap": dp_client == "cabi" or os.environ.get("CTX_DP_OVERLAP", "0") == "1"}
         except Exception as e:                      # diagnostics must never cost the bench line
             line["comm"] = {"error": repr(e)}
     if rank == 0:

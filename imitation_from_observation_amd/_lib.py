@@ -16,7 +16,15 @@ CTX_DP_UNIQUE_ID_BYTES = 128
 
 
 class CtxConfig(ctypes.Structure):
-    _fields_ = [(n, ctypes.c_int32) for n in ("variant", "H", "W", "C", "df_dim", "featsize", "max_batch", "precision")]
+    """ctx_config of include/ctxtrans.h (ABI 2).  Trailing fields default to zero = the reference's defaults."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("variant", "H", "W", "C", "df_dim", "featsize", "max_batch", "precision")] + \
+               [("strides", ctypes.c_int32 * 4), ("kernels", ctypes.c_int32 * 4), ("filters", ctypes.c_int32 * 4),
+                ("keep_prob", ctypes.c_float), ("loss_terms", ctypes.c_int32)]
+
+
+CTX_LOSS_RECON1, CTX_LOSS_RECON2, CTX_LOSS_SIM = 1, 2, 4
+# ablations_code/ablations.py:175-182: ablation_type -> terms of `loss`
+LOSS_ABLATIONS = {"None": 7, "L2": 3, "L2L3": 1, "L1": 6}
 
 
 class CtxProfEntry(ctypes.Structure):

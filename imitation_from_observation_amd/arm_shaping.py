@@ -44,14 +44,17 @@ class ContextSkipNew:
 
     variant = "skipnew"
 
-    def build(self, image, device=0, seed=None):
-        """`image`: the placeholder's shape (3, batch, H, W, 3) or an array of that shape."""
+    def build(self, image, device=0, seed=None, ablation_type="None", keep_prob=None):
+        """`image`: the placeholder's shape (3, batch, H, W, 3) or an array of that shape.  ablation_type: the loss switch the
+        model classes of ablations_code/ablations.py take in build() (:175-182).  keep_prob: ContextAEReal's dropout keep
+        probability in training (ablations.py:544 feeds 0.5; the sampler's graph has 1.0)."""
         shape = tuple(getattr(image, "shape", image))
         if len(shape) != 5 or shape[0] != 3 or shape[-1] != self.c_dim:
             raise ValueError(f"expected (3, batch, H, W, {self.c_dim}), got {shape}")
         self.batch_size, self.output_height, self.output_width = shape[1], shape[2], shape[3]
         self.translator = Translator(self.output_height, self.output_width, self.df_dim, self.featsize,
-                                     max_batch=self.batch_size, device=device, variant=self.variant)
+                                     max_batch=self.batch_size, device=device, variant=self.variant, ablation_type=ablation_type,
+                                     keep_prob=keep_prob)
         if seed is not None:
             self.translator.init_params(seed)              # tf.global_variables_initializer
         return self
@@ -121,13 +124,15 @@ class ContextAEInception2(ContextSkipNew):
     variant = "inception2"
 
     def __init__(self, strides, kernels, filters):
-        strides, kernels, filters = list(strides), list(kernels), list(filters)
-        d = filters[3] // 8 if len(filters) == 4 else 0
-        if strides != [1, 2, 1, 2] or kernels != [3, 3, 3, 3] or d <= 0 or filters != [16 * d, 16 * d, 8 * d, 8 * d]:
-            raise ValueError("libctxtrans builds ContextAEInception2 as strides [1,2,1,2], kernels [3,3,3,3], filters "
-                             f"[16d,16d,8d,8d] (the sampler's only instantiation, base.py:126); got {strides}, {kernels}, {filters}")
+        """The reference's three lists (arm_shaping.py:1787-1803): s1..s4, k1..k4 (k x k), f1..f4; the decoder mirrors them.
+        libctxtrans builds strides 1 | 2, kernel sizes 1..5 and filter counts that are multiples of 32."""
+        strides, kernels, filters = [int(v) for v in strides], [int(v) for v in kernels], [int(v) for v in filters]
+        if not (len(strides) == len(kernels) == len(filters) == 4):
+            raise ValueError("strides, kernels and filters have four entries each (arm_shaping.py:1801-1803)")
+        if any(s not in (1, 2) for s in strides) or any(not 1 <= k <= 5 for k in kernels) or any(f <= 0 or f % 32 for f in filters):
+            raise ValueError(f"libctxtrans builds strides 1|2, kernels 1..5, filters multiples of 32; got {strides}, {kernels}, {filters}")
         self.strides, self.kernels, self.filters = strides, kernels, filters
-        self.df_dim = self.gf_dim = d
+        self.df_dim = self.gf_dim = max(filters[3] // 8, 4)
         self.featsize = 1024                               # hard-coded in build(), arm_shaping.py:1797
         self.translator = None
         for f in _FETCHES:
@@ -139,7 +144,8 @@ class ContextAEInception2(ContextSkipNew):
             raise ValueError(f"expected (3, batch, h, w, C) feature maps, got {shape}")
         self.batch_size, self.output_height, self.output_width, self.c_dim = shape[1:]
         self.translator = Translator(self.output_height, self.output_width, self.df_dim, self.featsize, max_batch=self.batch_size,
-                                     device=device, variant=self.variant, C=self.c_dim, precision=precision)
+                                     device=device, variant=self.variant, C=self.c_dim, precision=precision,
+                                     strides=self.strides, kernels=self.kernels, filters=self.filters)
         if seed is not None:
             self.translator.init_params(seed)
         return self

@@ -191,14 +191,27 @@ int check_cfg(const ctx_config* c, ctx_handle* h) {
     if (!c) return fail(h, CTX_E_INVALID, "cfg is NULL");
     if (c->variant != CTX_VARIANT_SKIPNEW && c->variant != CTX_VARIANT_REAL && c->variant != CTX_VARIANT_INCEPTION2)
         return fail(h, CTX_E_INVALID, "unsupported variant %d", c->variant);
-    if (c->variant == CTX_VARIANT_INCEPTION2) {   // feature maps [h, w, C], filters 16d/16d/8d/8d, k 3, strides 1/2/1/2
+    if (c->loss_terms < 0 || c->loss_terms > 7) return fail(h, CTX_E_INVALID, "loss_terms must be a mask of CTX_LOSS_RECON1 | CTX_LOSS_RECON2 | CTX_LOSS_SIM (0 = all)");
+    if (!(c->keep_prob >= 0.f && c->keep_prob <= 1.f)) return fail(h, CTX_E_INVALID, "keep_prob must lie in [0, 1] (0 or 1: no dropout)");
+    if (c->keep_prob > 0.f && c->keep_prob < 1.f && c->variant != CTX_VARIANT_REAL)
+        return fail(h, CTX_E_INVALID, "keep_prob: only ContextAEReal has dropout in its graph (arm_shaping.py:1637-1661)");
+    if (c->variant == CTX_VARIANT_INCEPTION2) {   // feature maps [h, w, C]; ContextAEInception2(strides, kernels, filters)
         if (c->C <= 0 || c->C % 32) return fail(h, CTX_E_INVALID, "C (feature channels) must be a positive multiple of 32");
-        if (c->df_dim <= 0 || c->df_dim % 4) return fail(h, CTX_E_INVALID, "df_dim must be a multiple of 4 (filters 16d/16d/8d/8d)");
+        bool any_f = false, all_f = true;
+        for (int k = 0; k < 4; ++k) { any_f = any_f || c->filters[k]; all_f = all_f && c->filters[k]; }
+        if (any_f != all_f) return fail(h, CTX_E_INVALID, "filters: give all four counts or none");
+        if (!all_f && (c->df_dim <= 0 || c->df_dim % 4)) return fail(h, CTX_E_INVALID, "df_dim must be a multiple of 4 (default filters 16d/16d/8d/8d)");
+        for (int k = 0; k < 4; ++k) {
+            if (c->filters[k] < 0 || c->filters[k] % 32) return fail(h, CTX_E_INVALID, "filters[%d] = %d: filter counts must be multiples of 32", k, c->filters[k]);
+            if (c->kernels[k] < 0 || c->kernels[k] > 5) return fail(h, CTX_E_INVALID, "kernels[%d] = %d: kernel sizes 1..5 (k x k) are built", k, c->kernels[k]);
+            if (c->strides[k] < 0 || c->strides[k] > 2) return fail(h, CTX_E_INVALID, "strides[%d] = %d: strides 1 and 2 are built", k, c->strides[k]);
+        }
         if (c->featsize <= 0 || c->featsize % 32) return fail(h, CTX_E_INVALID, "featsize must be a multiple of 32");
         if (c->H <= 0 || c->W <= 0 || c->max_batch <= 0) return fail(h, CTX_E_INVALID, "H, W, max_batch must be positive");
         int hc = c->H, wc = c->W;
         for (int k = 0; k < 4; ++k) {
-            const int s = (k & 1) && !(hc == 1 && wc == 1) ? 2 : 1;
+            const int sk = c->strides[k] ? c->strides[k] : ((k & 1) ? 2 : 1);
+            const int s = sk == 2 && !(hc == 1 && wc == 1) ? 2 : 1;
             if (hc % s || wc % s) return fail(h, CTX_E_INVALID, "feature grid %dx%d: a stride-2 layer meets an odd grid larger than 1x1", c->H, c->W);
             hc /= s; wc /= s;
         }
@@ -355,6 +368,9 @@ const float* c4of(const ctx_handle* h, const float* p3) {
     return h->dout4 + (p3 - h->dout) / 3 * 4;
 }
 void pack_c4(ctx_handle* h, const float* p3, int64_t npix) { pack3to4(h->stream, p3, const_cast<float*>(c4of(h, p3)), npix); }
+
+// terms of `loss` (ctx_config.loss_terms; 0 = all)
+int loss_terms_of(const ctx_handle* h) { return h->cfg.loss_terms ? h->cfg.loss_terms : 7; }
 
 SplitWs ws_of(ctx_handle* h) { return SplitWs{h->slab, h->slab_floats, h->cfg.precision, h->gen ? 0 : 7}; }
 
@@ -630,7 +646,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
     float* src_z = h->Z + 2ll * B * F;
     {
         ProfScope ps(h, "losses", K_EW, 0.0);
-        losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars);
+        losses(h->stream, h->out, h->img, h->dout, npi, B, h->Z, tgt_z, h->dsim2, F, sim_batch, h->scratch, h->scalars, 0, loss_terms_of(h));
         if (!use_dc3(h)) pack_c4(h, h->dout, 2ll * B * h->H * h->W);
     }
 
@@ -1292,7 +1308,7 @@ int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const
     HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
     forward(h, B, MODE_TRAIN);
-    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
     return CTX_OK;
@@ -1406,7 +1422,7 @@ int ctx_eval(ctx_handle* h, const float* src, const float* ctxf, const float* tg
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_f32(h, src, ctxf, tgt, B));
     forward(h, B, MODE_TRAIN);
-    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
     h->last_B = B;
     const size_t bytes = (size_t)B * h->npi * sizeof(float);
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1609,7 +1625,7 @@ int ctx_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* cho
     HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
     forward(h, B, MODE_TRAIN);
-    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
     h->last_B = B;
     const size_t bytes = (size_t)B * h->npi * sizeof(float);
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NTHREADS) void loss_partial_kernel(const float* __r
                                                                 float* __restrict__ dout, int64_t half,
                                                                 const float* __restrict__ tz, const float* __restrict__ tgt_z,
                                                                 float* __restrict__ dsim2, int64_t nz, float csim,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, float w1, float w2) {
     __shared__ float sh[4];
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     const int64_t start = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4;
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(NTHREADS) void loss_partial_kernel(const float* __r
         const float4 db = make_float4(b.x - t.x, b.y - t.y, b.z - t.z, b.w - t.w);
         s1 += da.x * da.x + da.y * da.y + da.z * da.z + da.w * da.w;
         s2 += db.x * db.x + db.y * db.y + db.z * db.z + db.w * db.w;
-        if (dout) {
-            *reinterpret_cast<float4*>(dout + i) = da;
-            *reinterpret_cast<float4*>(dout + half + i) = db;
+        if (dout) {               // seeds of the backward pass: d (w1 recon1 + w2 recon2) / d out (w = 1: the value itself, bit for bit)
+            *reinterpret_cast<float4*>(dout + i) = make_float4(w1 * da.x, w1 * da.y, w1 * da.z, w1 * da.w);
+            *reinterpret_cast<float4*>(dout + half + i) = make_float4(w2 * db.x, w2 * db.y, w2 * db.z, w2 * db.w);
         }
     }
     for (int64_t i = start; i < nz; i += stride) {
@@ -302,31 +302,31 @@ __global__ __launch_bounds__(NTHREADS) void loss_partial_kernel(const float* __r
 
 // One wave: lane l adds partials l, l + 64, ... in double, then a fixed xor tree over the lanes (deterministic).  The
 // single-thread loop it replaces took 33 us at the head of the backward chain.
-__global__ void loss_final_kernel(const float* __restrict__ partial, int nblk, double inv_nz, float* __restrict__ scalars) {
+__global__ void loss_final_kernel(const float* __restrict__ partial, int nblk, double inv_nz, float* __restrict__ scalars, int terms) {
     double a = 0, b = 0, c = 0;
     for (int i = threadIdx.x; i < nblk; i += 64) { a += partial[i]; b += partial[LOSS_BLOCKS + i]; c += partial[2 * LOSS_BLOCKS + i]; }
     for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
     if (threadIdx.x != 0) return;
     const double r1 = 0.5 * a, r2 = 0.5 * b, sim = c * inv_nz * 1e3;
-    scalars[0] = (float)(r1 + r2 + sim);
+    scalars[0] = (float)((terms & 1 ? r1 : 0.0) + (terms & 2 ? r2 : 0.0) + (terms & 4 ? sim : 0.0));
     scalars[1] = (float)sim;
     scalars[2] = (float)r1;
     scalars[3] = (float)r2;
 }
 
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
-            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real) {
+            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real, int terms) {
     // F = row stride of the code buffers (zero-padded beyond F_real); the simloss mean runs over B x F_real
     if (F_real <= 0) F_real = F;
     const int64_t half = npi * B, nz = (int64_t)B * F;
     int64_t blocks = (half / 4 + NTHREADS - 1) / NTHREADS;
     if (blocks > LOSS_BLOCKS) blocks = LOSS_BLOCKS;
     if (blocks < 1) blocks = 1;
-    const float csim = (float)(2e3 / ((double)sim_batch * F_real));
+    const float csim = terms & 4 ? (float)(2e3 / ((double)sim_batch * F_real)) : 0.f;
     hipLaunchKernelGGL(loss_partial_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, out, tgt, dout, half, tz, tgt_z,
-                       dsim2, nz, csim, scratch);
+                       dsim2, nz, csim, scratch, terms & 1 ? 1.f : 0.f, terms & 2 ? 1.f : 0.f);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, (int)blocks,
-                       1.0 / ((double)B * F_real), scalars);
+                       1.0 / ((double)B * F_real), scalars, terms);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -96,8 +96,10 @@ void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t n
 //   tz, tgt_z [B, F]; dsim2 (nullable) [2B, F] = [+c (tz - tgt_z); -c (tz - tgt_z)], c = 2e3/(sim_batch F)
 //   scalars[4] = {loss, simloss, recon1, recon2};  scratch: >= 4 * LOSS_BLOCKS floats
 constexpr int LOSS_BLOCKS = 512;
+//   terms: CTX_LOSS_* mask of the terms that make up `loss` (ablations_code/ablations.py:175-182): an excluded term is still
+//   reported in scalars[1..3] but contributes neither to scalars[0] nor to the backward seeds
 void losses(hipStream_t s, const float* out, const float* tgt, float* dout, int64_t npi, int B, const float* tz,
-            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real = 0);
+            const float* tgt_z, float* dsim2, int F, int sim_batch, float* scratch, float* scalars, int F_real = 0, int terms = 7);
 
 // per-frame reward cost (rllab/sampler/base.py:243-249): costs[j] = |means[j % bs] - feat[j]|^2 + scale * |imgs[j % bs] - x[j]|^2
 // (ablation 1: image term only, 2: feature term only)

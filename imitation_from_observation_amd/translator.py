@@ -56,15 +56,21 @@ class Translator:
     PRECISIONS = {"f32": _lib.CTX_PREC_F32, "bf16x3": _lib.CTX_PREC_BF16X3}
 
     def __init__(self, H=64, W=64, df_dim=64, featsize=1024, max_batch=256, device=0, stream=None, arena_ptr=None,
-                 variant="skipnew", precision=None, C=3):
+                 variant="skipnew", precision=None, C=3, strides=None, kernels=None, filters=None, keep_prob=None, ablation_type="None"):
         """variant "skipnew": ContextSkipNew (sampler names push/reach/strike/throw); "real": ContextAEReal
         (names real/sweep; pass H=36, W=64, featsize=100 -- df_dim is ignored, rllab/sampler/base.py:134-137);
         "inception2": ContextAEInception2 on Mixed_7c feature maps (mode 'oursinception'; pass the feature grid as H, W
-        and C=2048; float inputs only: translate_f32 / encode_f32 / train_step / evaluate)."""
+        and C=2048; float inputs only: translate_f32 / encode_f32 / train_step / evaluate; `strides`, `kernels`, `filters` are the
+        constructor lists of ContextAEInception2 (arm_shaping.py:1787-1803), None = the sampler's [1,2,1,2] / [3,3,3,3] /
+        [16d,16d,8d,8d]).
+        keep_prob (variant "real" only): tf.nn.dropout keep probability of the training graph (arm_shaping.py:1637-1661;
+        ablations_code/ablations.py:544 feeds 0.5); None / 1: none.  ablation_type: which terms Adam minimises
+        (ablations.py:175-182): "None" = recon1 + recon2 + simloss, "L2" = recon1 + recon2, "L2L3" = recon1, "L1" = recon2 + simloss."""
         precision = precision or os.environ.get("CTX_PRECISION", "f32")     # "f32" (exact) | "bf16x3" (split-bf16 products)
         self._lib = _lib.load()
         self.variant, self.precision = variant, precision
-        self.cfg = CtxConfig(self.VARIANTS[variant], H, W, C, df_dim, featsize, max_batch, self.PRECISIONS[precision])
+        self.cfg = self.make_config(variant, H, W, C, df_dim, featsize, max_batch, precision, strides, kernels, filters, keep_prob, ablation_type)
+        self.keep_prob, self.ablation_type = keep_prob, ablation_type
         self.H, self.W, self.C, self.df_dim, self.featsize, self.max_batch = H, W, C, df_dim, featsize, max_batch
         self.device = device
         self._h = ctypes.c_void_p()
@@ -98,13 +104,31 @@ class Translator:
         _lib.check(self._lib, self._h, rc)
 
     @staticmethod
-    def param_total(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3):
-        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, C, df_dim, featsize, 1, 0)
+    def make_config(variant, H, W, C, df_dim, featsize, max_batch, precision="f32", strides=None, kernels=None, filters=None,
+                    keep_prob=None, ablation_type="None"):
+        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, C, df_dim, featsize, max_batch, Translator.PRECISIONS[precision or "f32"])
+        for name, lst in (("strides", strides), ("kernels", kernels), ("filters", filters)):
+            if lst is not None:
+                if variant != "inception2":
+                    raise ValueError(f"{name}: only ContextAEInception2 takes them (arm_shaping.py:1787)")
+                if len(lst) != 4:
+                    raise ValueError(f"{name} must have 4 entries")
+                setattr(cfg, name, (ctypes.c_int32 * 4)(*[int(v) for v in lst]))
+        if keep_prob is not None:
+            cfg.keep_prob = float(keep_prob)
+        if ablation_type not in _lib.LOSS_ABLATIONS:
+            raise ValueError(f"ablation_type must be one of {sorted(_lib.LOSS_ABLATIONS)}")
+        cfg.loss_terms = _lib.LOSS_ABLATIONS[ablation_type]
+        return cfg
+
+    @staticmethod
+    def param_total(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3, strides=None, kernels=None, filters=None):
+        cfg = Translator.make_config(variant, H, W, C, df_dim, featsize, 1, "f32", strides, kernels, filters)
         return int(_lib.load().ctx_param_total_for(ctypes.byref(cfg)))
 
     @staticmethod
-    def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3):
-        cfg = CtxConfig(Translator.VARIANTS[variant], H, W, C, df_dim, featsize, 1, 0)
+    def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3, strides=None, kernels=None, filters=None):
+        cfg = Translator.make_config(variant, H, W, C, df_dim, featsize, 1, "f32", strides, kernels, filters)
         return int(_lib.load().ctx_arena_bytes(ctypes.byref(cfg))) // 4
 
     # ------------------------------------------------------------------ parameters (tf.train.Saver)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CTX_ABI_VERSION 1
+#define CTX_ABI_VERSION 2   /* 2: ctx_config carries strides / kernels / filters / keep_prob / loss_mode */
 
 enum {
     CTX_OK = 0,
@@ -52,9 +52,12 @@ enum {
 
 enum {
     CTX_VARIANT_SKIPNEW = 0, /* ContextSkipNew, gym/envs/mujoco/arm_shaping.py:1260-1354 */
-    CTX_VARIANT_INCEPTION2 = 2, /* ContextAEInception2, arm_shaping.py:1786-1894 (mode 'oursinception'), built as
-                                   strides [1,2,1,2], kernels [3,3,3,3], filters [16d,16d,8d,8d] (d = df_dim = 64:
-                                   rllab/sampler/base.py:126).  Inputs are Inception-v3 Mixed_7c FEATURE MAPS, f32
+    CTX_VARIANT_INCEPTION2 = 2, /* ContextAEInception2(strides, kernels, filters), arm_shaping.py:1786-1894 (mode
+                                   'oursinception').  ctx_config.strides / kernels / filters are the constructor's lists
+                                   (:1787-1803: s1..s4, k1..k4, f1..f4; the decoder mirrors them); all-zero lists mean the
+                                   sampler's instantiation strides [1,2,1,2], kernels [3,3,3,3], filters [16d,16d,8d,8d]
+                                   (d = df_dim = 64: rllab/sampler/base.py:126).  Strides 1 | 2, kernels 1..5 (k x k),
+                                   filters multiples of 32.  Inputs are Inception-v3 Mixed_7c FEATURE MAPS, f32
                                    [B, H, W, C] with C a multiple of 32 (2048; H = W = 2 for 125x125 frames, 8 for
                                    299x299); out = decode + tgtctx.  The uint8 entry points are refused: use *_f32. */
     CTX_VARIANT_REAL = 1     /* ContextAEReal, arm_shaping.py:1599-1684 (sampler names 'real', 'sweep'): shared
@@ -78,7 +81,21 @@ typedef struct ctx_config {
     int32_t featsize;   /* 1024 in the reference (arm_shaping.py:1277); multiple of 32 */
     int32_t max_batch;  /* largest B any later call will pass */
     int32_t precision;  /* CTX_PREC_*: arithmetic of the matrix contractions (0 = exact f32, the default) */
+    /* ---- ABI 2 (zero-initialise for the defaults) ---- */
+    int32_t strides[4]; /* CTX_VARIANT_INCEPTION2: s1..s4 of the constructor (0,0,0,0 = 1,2,1,2) */
+    int32_t kernels[4]; /*                          k1..k4 (0 = 3) */
+    int32_t filters[4]; /*                          f1..f4 (0 = 16d,16d,8d,8d) */
+    float keep_prob;    /* CTX_VARIANT_REAL: tf.nn.dropout keep probability of the TRAINING graph (arm_shaping.py:1637-1661; the
+                           module-level default is 1.0, :1476; ablations_code/ablations.py:544 feeds 0.5).  0 or 1 = no dropout.
+                           Inference fetches (ctx_translate / ctx_encode) and ctx_eval never drop (keep_prob = 1 is what the
+                           sampler's graph has). */
+    int32_t loss_terms; /* CTX_LOSS_* bits: which terms make up `loss`, i.e. what Adam minimises (0 = all three) */
 } ctx_config;
+
+/* `loss` of the training graph.  The reference's trainer minimises recon1 + recon2 + simloss (arm_shaping.py:1354); its ablation
+ * script switches terms off (ablations_code/ablations.py:175-182, 278-285):  "None" = all (7),  "L2" = recon1 + recon2 (3),
+ * "L2L3" = recon1 (1),  "L1" = recon2 + simloss (6).  All four scalars are reported whatever the mask. */
+enum { CTX_LOSS_RECON1 = 1, CTX_LOSS_RECON2 = 2, CTX_LOSS_SIM = 4 };
 
 typedef struct ctx_handle ctx_handle;
 

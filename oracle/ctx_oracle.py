@@ -287,9 +287,14 @@ def _decode(p, cfg, z, skips):
     return hs, cats
 
 
-def forward(p, src, ctx, tgt, cfg: SkipNewConfig):
+# ablations_code/ablations.py:175-182 (the same switch in every model class of that file): which terms make up `loss`
+LOSS_ABLATIONS = {"None": ("recon1", "recon2", "simloss"), "L2": ("recon1", "recon2"), "L2L3": ("recon1",), "L1": ("recon2", "simloss")}
+
+
+def forward(p, src, ctx, tgt, cfg: SkipNewConfig, ablation_type="None"):
     """Whole graph of ContextSkipNew.build.  Inputs are float arrays [B,H,W,C] in [-1,1]
-    (image[0]=src :1278, image[2]=tgt :1279, image[1]=ctx :1280)."""
+    (image[0]=src :1278, image[2]=tgt :1279, image[1]=ctx :1280).  ablation_type: the loss switch of
+    ablations_code/ablations.py:175-182 ("None" = the trainer's recon1 + recon2 + simloss)."""
     c = {"src": src, "ctx": ctx, "tgt": tgt}
     c["e_ctx"] = _encode(p, "conv_context", ctx, z_lrelu=False)      # :1282-1288
     c["e_src"] = _encode(p, "conv", src, z_lrelu=True)               # :1290-1298
@@ -310,7 +315,8 @@ def forward(p, src, ctx, tgt, cfg: SkipNewConfig):
         "recon1": 0.5 * np.sum((tgt - out) ** 2),                    # :1352  tf.nn.l2_loss
         "recon2": 0.5 * np.sum((tgt - out2) ** 2),                   # :1353
     }
-    res["loss"] = res["recon1"] + res["recon2"] + res["simloss"]     # :1354
+    res["loss"] = sum(res[t] for t in LOSS_ABLATIONS[ablation_type])  # :1354 / ablations.py:175-182
+    c["ablation_type"] = ablation_type
     return res, c
 
 
@@ -325,7 +331,9 @@ def backward(p, c, cfg: SkipNewConfig, sim_batch=None):
     B = tgt.shape[0]
     F = cfg.featsize
     tgt_z = c["e_tgt"][5]
-    dsim = (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)   # d simloss / d trans_z
+    terms = LOSS_ABLATIONS[c.get("ablation_type", "None")]
+    w1, w2 = float("recon1" in terms), float("recon2" in terms)
+    dsim = ("simloss" in terms) * (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)   # d simloss / d trans_z
 
     def acc(name, val):
         g[name] = val if g[name] is None else g[name] + val
@@ -351,8 +359,8 @@ def backward(p, c, cfg: SkipNewConfig, sim_batch=None):
         return dy @ p[f"{name}/Matrix"].T
 
     # decoder on translated z (recon1) and on tgt z (recon2)
-    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] - tgt)
-    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] - tgt)
+    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], w1 * (c["d1"][4] - tgt))
+    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], w2 * (c["d2"][4] - tgt))
     dtrans_z = lin_bwd("deconv/d_h0_lin", c["trans_z"], dz1_) + dsim
     dtgt_z = lin_bwd("deconv/d_h0_lin", tgt_z, dz2_) - dsim          # no stop-gradient on tgtimg_z
     # translate MLP

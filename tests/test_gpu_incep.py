@@ -116,8 +116,8 @@ def test_reference_model_interface(T):
     H, W, C, d, F, B = 2, 2, 64, 4, 1024, 3
     cfg, p, (src, ctx, tgt) = make(H, W, C, d, F, B, seed=4)
     res, _ = oi.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
-    with pytest.raises(ValueError, match="base.py:126"):
-        ContextAEInception2(strides=[2, 2, 2, 2], kernels=[3, 3, 3, 3], filters=[64, 64, 32, 32])
+    with pytest.raises(ValueError, match="strides 1.2"):
+        ContextAEInception2(strides=[3, 2, 2, 2], kernels=[3, 3, 3, 3], filters=[64, 64, 32, 32])
     m = ContextAEInception2(strides=[1, 2, 1, 2], kernels=[3, 3, 3, 3], filters=[16 * d, 16 * d, 8 * d, 8 * d])
     m.build((3, B, H, W, C))
     try:
@@ -139,3 +139,82 @@ def test_reference_model_interface(T):
         assert m.run(m.loss, image) != l0                                          # the step moved the parameters
     finally:
         m.translator.close()
+
+
+# ---- the class as the reference defines it: ContextAEInception2(strides, kernels, filters), arm_shaping.py:1786-1803 -------------
+def _param_case(H, W, C, F, strides, kernels, filters, B, seed):
+    cfg = oi.Incep2Config(H=H, W=W, C=C, featsize=F, strides=tuple(strides), kernels=tuple(kernels), filters=tuple(filters))
+    p = oi.init_params(cfg, 80 + seed, np.float64, stddev=0.05)
+    brng = np.random.default_rng(seed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * 0.05
+    rng = np.random.default_rng(seed)
+    feats = [np.maximum(rng.standard_normal((B, H, W, C)), 0).astype(np.float32) for _ in range(3)]
+    return cfg, p, feats
+
+
+@pytest.mark.parametrize("H,W,C,F,strides,kernels,filters,B", [
+    (8, 4, 32, 64, (2, 1, 2, 1), (5, 3, 3, 1), (32, 64, 32, 32), 3),        # other strides, mixed kernel sizes incl. 1x1 and 5x5
+    (8, 8, 32, 32, (2, 2, 1, 1), (3, 5, 3, 3), (32, 32, 64, 32), 2),        # two stride-2 layers in a row
+    (4, 4, 64, 64, (1, 1, 1, 1), (3, 3, 1, 5), (64, 32, 32, 32), 2),        # no down-sampling at all
+    (4, 4, 32, 32, (2, 2, 2, 2), (4, 2, 3, 3), (32, 32, 32, 32), 2),        # even kernels (SAME pads more behind than in front); 1x1 grids under stride 2
+    (4, 4, 32, 32, (1, 2, 1, 2), (3, 3, 3, 3), (32, 32, 32, 64), 64),       # position-major launches (>= 64 images)
+])
+def test_incep2_parametric_strides_kernels_filters(T, H, W, C, F, strides, kernels, filters, B):
+    cfg, p, (src, ctx, tgt) = _param_case(H, W, C, F, strides, kernels, filters, B, seed=B)
+    res, c = oi.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    g = oi.backward(p, c, cfg)
+    with T(H, W, df_dim=4, featsize=F, max_batch=B, variant="inception2", C=C, strides=strides, kernels=kernels, filters=filters) as tr:
+        assert [(n, s) for n, s, _ in tr.param_info()] == [(n, tuple(s)) for n, s in oi.param_specs(cfg)]
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(ev[k] - res[k]) <= 1e-5 * abs(res[k]) + 1e-6, k
+        assert relmax(ev["out"], res["out"]) < 1e-5 and relmax(ev["out2"], res["out2"]) < 1e-5
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        gg = tr.get_grads()
+        tol = 1e-4 if B < 64 else 1e-3                                        # (large batches: lrelu' flips at fp32 zero are not aligned)
+        for n in g:
+            assert relmax(gg[n], g[n]) < tol, n
+        pred, feat = tr.translate_f32(src, ctx[0])
+        opred, ofeat = oi.translate(p, src.astype(np.float64), ctx[0].astype(np.float64), cfg)
+        assert relmax(pred, opred) < 1e-5 and relmax(feat, ofeat) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["incep2_4x4x64_f32_b2", "incep2_8x4x32_k5331_s2121_b2"])
+def test_incep2_golden_fixtures(T, tag):
+    """The committed fixtures the TF recipe (tests/golden/make_tf_fixtures.py) reproduces with the unmodified reference class
+    (featsize 1024 hard-coded, :1797): outputs, scalars, gradient digests and the Adam trajectory through the C ABI."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", tag + ".npz"))
+    H, W, C, F = (int(v) for v in z["cfg"])
+    strides, kernels, filters = ([int(v) for v in z[k]] for k in ("strides", "kernels", "filters"))
+    cfg = oi.Incep2Config(H=H, W=W, C=C, featsize=F, strides=tuple(strides), kernels=tuple(kernels), filters=tuple(filters))
+    p = oi.init_params(cfg, int(z["pseed"]), np.float64, stddev=float(z["stddev"]))
+    brng = np.random.default_rng(int(z["pseed"]) + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = brng.standard_normal(p[n].shape) * float(z["stddev"])
+    B = int(z["B"])
+    src, ctx, tgt = z["src_f32"], z["ctx_f32"], z["tgt_f32"]
+    with T(H, W, df_dim=4, featsize=F, max_batch=B, variant="inception2", C=C, strides=strides, kernels=kernels, filters=filters) as tr:
+        tr.set_params(p)
+        ev = tr.evaluate(src, ctx, tgt)
+        np.testing.assert_allclose([ev["loss"], ev["simloss"], ev["recon1"], ev["recon2"]], z["scalars"], rtol=2e-5)
+        assert relmax(ev["out"], z["out"]) < 1e-5 and relmax(ev["out2"], z["out2"]) < 1e-5
+        iz, tz = tr.last_codes()
+        assert relmax(iz, z["input_z"]) < 1e-5 and relmax(tz, z["translated_z"]) < 1e-5
+        traj = [tr.train_step(src, ctx, tgt, lr=float(z["lr"])) for _ in range(int(z["steps"]))]
+        gdig = z["grad_digest"]
+        np.testing.assert_allclose([[t["loss"], t["simloss"], t["recon1"], t["recon2"]] for t in traj], z["train_scalars"], rtol=1e-4)
+        tr2_grads = None
+    with T(H, W, df_dim=4, featsize=F, max_batch=B, variant="inception2", C=C, strides=strides, kernels=kernels, filters=filters) as tr:
+        tr.set_params(p)
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        for i, (n, gv) in enumerate(tr.get_grads().items()):
+            a = np.asarray(gv, np.float64).reshape(-1)
+            dig = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())])
+            assert abs(dig[2] - gdig[i][2]) <= 1e-4 * gdig[i][2] + 1e-12, n
+            assert abs(dig[0] - gdig[i][0]) <= 1e-4 * gdig[i][1] + 1e-12, n
+            assert relmax(a[:64], z["grad_head"][i][:min(64, a.size)]) < 1e-3 or np.abs(z["grad_head"][i]).max() < 1e-12, n

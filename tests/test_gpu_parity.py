@@ -401,3 +401,40 @@ def test_max_batch_beyond_32bit_offsets_is_refused(T):
     from imitation_from_observation_amd import CtxError
     with pytest.raises(CtxError, match="2 GiB"):
         T(64, 64, 64, 1024, max_batch=8192)
+
+
+@pytest.mark.parametrize("ablation", ["L2", "L2L3", "L1"])
+def test_loss_ablations_of_the_ablation_script(ablation):
+    """ablations_code/ablations.py:175-182: `loss` = recon1 + recon2 ("L2"), recon1 ("L2L3"), recon2 + simloss ("L1").  The four scalars
+    are reported as always; `loss` and every gradient are those of the selected terms (oracle with the same switch)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import Translator
+    from imitation_from_observation_amd.arm_shaping import ContextSkipNew
+    H = W = 32
+    d, F, B = 32, 128, 4
+    cfg = o.SkipNewConfig(H=H, W=W, df_dim=d, gf_dim=d, featsize=F)
+    p = o.init_params(cfg, 99, np.float64, stddev=0.05)
+    rng = np.random.default_rng(5)
+    src, ctx, tgt = (rng.uniform(-1, 1, (B, H, W, 3)).astype(np.float32) for _ in range(3))
+    res, c = o.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg, ablation_type=ablation)
+    g = o.backward(p, c, cfg)
+    full, _ = o.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    assert res["loss"] != full["loss"]
+    with Translator(H, W, d, F, max_batch=B, ablation_type=ablation) as tr:
+        tr.set_params(p)
+        sc = tr.train_step(src, ctx, tgt, lr=0.0)
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(sc[k] - res[k]) <= 1e-5 * abs(res[k]), k
+        gg = tr.get_grads()
+        for n in g:
+            den = np.abs(g[n]).max()
+            if den == 0:                                   # a term that is switched off leaves some tensors without gradient
+                assert np.abs(gg[n]).max() == 0, n
+            else:
+                assert np.abs(gg[n] - g[n]).max() <= 1e-4 * den, n
+        ev = tr.evaluate(src, ctx, tgt)
+        assert abs(ev["loss"] - res["loss"]) <= 1e-5 * abs(res["loss"])
+    with pytest.raises(ValueError):
+        Translator(H, W, d, F, max_batch=B, ablation_type="L3")
