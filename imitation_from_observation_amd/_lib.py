@@ -82,6 +82,7 @@ SIGNATURES = {
     "ctx_reward_set_cache": (_c.c_int, [_P, _c.c_int, _F, _F, _c.c_int]),
     "ctx_reward_costs": (_c.c_int, [_P, _c.c_int, _U8, _c.c_int, _c.c_float, _c.c_int, _F]),
     "ctx_train_step": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _c.c_float, _F]),
+    "ctx_set_dropout_seed": (_c.c_int, [_P, _c.c_uint64]),
     "ctx_train_step_u8": (_c.c_int, [_P, _U8, _U8, _U8, _c.c_int, _c.c_float, _F]),
     "ctx_demos_upload": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),
     "ctx_train_step_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _c.c_float, _F]),

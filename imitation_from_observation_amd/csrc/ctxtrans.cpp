@@ -124,6 +124,9 @@ struct ctx_handle {
     bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
     int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
     int dp_rc = 0;                // result of the tail bucket's collective (started from inside backward)
+    // tf.nn.dropout (CTX_VARIANT_REAL with keep_prob < 1): on only while a TRAINING step (forward + backward) is being enqueued
+    bool drop_on = false;
+    uint64_t drop_seed = 0;
 
     // per-op profiling (ctx_profile_step): HIP events around every launch group
     bool prof_on = false;
@@ -1323,10 +1326,18 @@ int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_c
     HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->drop_on = true;      // (dropout belongs to the training graph only)
     forward(h, B, MODE_TRAIN);
     backward(h, B, sim_batch ? sim_batch : B);
+    h->drop_on = false;
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_set_dropout_seed(ctx_handle* h, uint64_t seed) {
+    if (!h) return CTX_E_INVALID;
+    h->drop_seed = seed;
     return CTX_OK;
 }
 
@@ -1391,8 +1402,10 @@ int ctx_train_step(ctx_handle* h, const float* src, const float* ctxf, const flo
     if (!src || !ctxf || !tgt) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_f32(h, src, ctxf, tgt, B));
+    h->drop_on = true;      // (dropout belongs to the training graph only)
     forward(h, B, MODE_TRAIN);
     backward(h, B, B);
+    h->drop_on = false;
     TRY(adam_step(h, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1408,8 +1421,10 @@ int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx8, co
     HIP_TRY(h, hipMemcpyAsync(h->u8 + nb, src, nb, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->u8 + 2 * nb, ctx8, nb, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, h->u8, h->img, 3 * (int64_t)nb);
+    h->drop_on = true;      // (dropout belongs to the training graph only)
     forward(h, B, MODE_TRAIN);
     backward(h, B, B);
+    h->drop_on = false;
     TRY(adam_step(h, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1444,8 +1459,10 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
         HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
         h->prof_on = true;
         h->prof_cursor = 0;
+        h->drop_on = true;      // (dropout belongs to the training graph only)
         forward(h, B, MODE_TRAIN);
         backward(h, B, B);
+        h->drop_on = false;
         const int rc = adam_step(h, lr);
         h->prof_on = false;
         if (rc != CTX_OK) return rc;
@@ -1539,12 +1556,14 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    h->drop_on = true;
     forward(h, B, MODE_TRAIN);
     // two buckets: [split, Ppad) = translate/* + deconv/* leaves from inside backward (fire_bucket) and travels while the
     // encoders' backward runs; [0, split) = the encoders after it.  simloss is a mean over the GLOBAL batch (arm_shaping.py:1345).
     h->dp_in_step = true; h->dp_split = -1; h->dp_rc = CTX_OK;
     backward(h, B, B * h->dp_world);
     h->dp_in_step = false;
+    h->drop_on = false;
     TRY(h->dp_rc);
     const int64_t split = h->dp_split >= 0 ? h->dp_split : h->Ppad;
     TRY(dp_reduce_range(h, 0, split));
@@ -1605,8 +1624,10 @@ int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_
     HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
+    h->drop_on = true;      // (dropout belongs to the training graph only)
     forward(h, B, MODE_TRAIN);
     backward(h, B, B);
+    h->drop_on = false;
     TRY(adam_step(h, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));

@@ -489,6 +489,61 @@ __global__ __launch_bounds__(NTHREADS) void lrelu_mask_kernel(float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tf.nn.dropout of ContextAEReal's training graph (arm_shaping.py:1637-1661): factors M = mask / keep_prob from a counter-based
+// hash of (seed, step, site, element index), so that a test can hand the CPU checker exactly the masks a step used (the hash is
+// documented in include/ctxtrans.h: ctx_set_dropout_seed).  The tensors are a few hundred KB: plain elementwise kernels.
+//   drop_factors  M[row][c] for a [rows, ld] buffer whose row holds groups of gp slots with gr real values in front
+//                 (channel padding of the flatten; gp = gr = ld for plain rows): element index = row * ncols + group * gr + w
+//   ew_mul        out[r][c] = x[r][c] * M[r][c]   (own row strides: the concat of site 3 is assembled this way)
+//   drop_fin      out = (raw * M + add1 + add2) * lrelu'(act)   -- the input gradient behind a dropout site
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t step, uint32_t site, uint32_t idx) {
+    uint32_t x = idx * 0x9E3779B1u + site * 0x85EBCA77u + step * 0xC2B2AE3Du + seed * 0x27D4EB2Fu;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(NTHREADS) void drop_factors_kernel(float* __restrict__ M, int rows, int ld, int gp, int gr, int ncols,
+                                                                uint32_t thr, float inv_keep, uint32_t seed, uint32_t step, uint32_t site) {
+    const int64_t n = (int64_t)rows * ld;
+    for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * NTHREADS) {
+        const int row = (int)(i / ld), c = (int)(i - (int64_t)row * ld), grp = c / gp, w = c - grp * gp, col = grp * gr + w;
+        const bool real = w < gr && col < ncols;
+        M[i] = real && drop_hash(seed, step, site, (uint32_t)row * (uint32_t)ncols + (uint32_t)col) < thr ? inv_keep : 0.f;
+    }
+}
+void drop_factors(hipStream_t s, float* M, int rows, int ld, int gp, int gr, int ncols, float keep_prob, uint32_t seed, uint32_t step, int site) {
+    double t = (double)keep_prob * 4294967296.0;
+    const uint32_t thr = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    hipLaunchKernelGGL(drop_factors_kernel, dim3(ew_blocks((int64_t)rows * ld)), dim3(NTHREADS), 0, s, M, rows, ld, gp, gr, ncols, thr,
+                       1.f / keep_prob, seed, step, (uint32_t)site);
+}
+__global__ __launch_bounds__(NTHREADS) void ew_mul_kernel(float* __restrict__ out, int ldo, const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ M, int ldm, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * NTHREADS) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        out[(int64_t)r * ldo + c] = x[(int64_t)r * ldx + c] * M[(int64_t)r * ldm + c];
+    }
+}
+void ew_mul(hipStream_t s, float* out, int ldo, const float* x, int ldx, const float* M, int ldm, int rows, int cols) {
+    hipLaunchKernelGGL(ew_mul_kernel, dim3(ew_blocks((int64_t)rows * cols)), dim3(NTHREADS), 0, s, out, ldo, x, ldx, M, ldm, rows, cols);
+}
+__global__ __launch_bounds__(NTHREADS) void drop_fin_kernel(float* __restrict__ out, const float* __restrict__ raw, const float* __restrict__ M,
+                                                            const float* __restrict__ add1, const float* __restrict__ add2,
+                                                            const float* __restrict__ act, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * NTHREADS) {
+        float v = raw[i] * M[i];
+        if (add1) v += add1[i];
+        if (add2) v += add2[i];
+        if (act) v *= act[i] >= 0.f ? 1.f : LEAK;
+        out[i] = v;
+    }
+}
+void drop_fin(hipStream_t s, float* out, const float* raw, const float* M, const float* add1, const float* add2, const float* act, int64_t n) {
+    hipLaunchKernelGGL(drop_fin_kernel, dim3(ew_blocks(n)), dim3(NTHREADS), 0, s, out, raw, M, add1, add2, act, n);
+}
+
 void lrelu_mask(hipStream_t s, float* g, const float* act, int64_t n) {
     hipLaunchKernelGGL(lrelu_mask_kernel, dim3(ew_blocks(n / 4)), dim3(NTHREADS), 0, s, g, act, n);
 }

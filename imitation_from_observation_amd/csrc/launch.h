@@ -110,6 +110,12 @@ void reward_costs(hipStream_t s, const float* feat, int ldf, int F, const float*
 constexpr int COLSUM_SPLITS = 512;
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out);
 
+// tf.nn.dropout of ContextAEReal's training graph (kernels.hip): factors mask / keep_prob from a hash of (seed, step, site, element),
+// an elementwise product with own row strides, and  out = (raw * M + add1 + add2) * lrelu'(act)  (add1 / add2 / act nullable)
+void drop_factors(hipStream_t s, float* M, int rows, int ld, int gp, int gr, int ncols, float keep_prob, uint32_t seed, uint32_t step, int site);
+void ew_mul(hipStream_t s, float* out, int ldo, const float* x, int ldx, const float* M, int ldm, int rows, int cols);
+void drop_fin(hipStream_t s, float* out, const float* raw, const float* M, const float* add1, const float* add2, const float* act, int64_t n);
+
 // g *= (act >= 0 ? 1 : 0.2)
 void lrelu_mask(hipStream_t s, float* g, const float* act, int64_t n);
 

@@ -318,6 +318,10 @@ class Translator:
         self._ck(self._lib.ctx_train_step(self._h, _fp(src), _fp(ctx), _fp(tgt), B, float(lr), _fp(sc)))
         return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
+    def set_dropout_seed(self, seed):
+        """Seed of the dropout masks (variant "real" with keep_prob < 1); include/ctxtrans.h: ctx_set_dropout_seed."""
+        self._ck(self._lib.ctx_set_dropout_seed(self._h, ctypes.c_uint64(int(seed))))
+
     def train_step_u8(self, src, ctx, tgt, lr=1e-4):
         src = _u8(src)
         shp = (src.shape[0], self.H, self.W, 3)

@@ -160,6 +160,12 @@ int ctx_reward_costs(ctx_handle* h, int vp, const uint8_t* frames, int npaths, f
  * recon2} of the forward pass before the update.  Adam: TF defaults b1 .9, b2 .999, eps 1e-8. */
 int ctx_train_step(ctx_handle* h, const float* src, const float* ctx, const float* tgt, int B,
                    float lr, float scalars[4]);
+/* CTX_VARIANT_REAL with 0 < keep_prob < 1: seed of the dropout masks of the training entry points (ctx_train_step*,
+ * ctx_dev_forward_backward, ctx_dp_train_step).  The factor of element e at dropout site s in the step that follows `t` Adam updates
+ * is  (hash32(seed, t, s, e) < keep_prob * 2^32) / keep_prob  -- a counter-based hash (csrc/kernels.hip: drop_hash) that
+ * oracle/ctx_oracle_real.py restates, so a step can be checked with the masks it used.  Default seed 0.  (TensorFlow's own random
+ * stream is not reproducible from outside; tf.nn.dropout's arithmetic x * mask / keep_prob is.) */
+int ctx_set_dropout_seed(ctx_handle* h, uint64_t seed);
 /* Same on uint8 frames, preprocessed on device with (x/255 - 0.5)*2. */
 int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx, const uint8_t* tgt,
                       int B, float lr, float scalars[4]);

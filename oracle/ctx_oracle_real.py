@@ -85,24 +85,66 @@ def flatten(tree, cfg, dtype=None):
         dtype or next(iter(tree.values())).dtype)
 
 
-def _encode(p, img):
-    """arm_shaping.py:1633-1640."""
+# --------------------------------------------------------------------------------------------------------------------
+# tf.nn.dropout(x, keep_prob) = x * floor(keep_prob + U) / keep_prob at six sites of the TRAINING graph (arm_shaping.py:1637-1661;
+# keep_prob is a module-level placeholder_with_default(1.0), :1476; ablations_code/ablations.py:544 feeds 0.5 when it trains this
+# class, 1.0 when it validates, :556).  TensorFlow's random stream cannot be reproduced, and need not be: parity for a random op
+# means "given the same masks, the same numbers".  The HIP path draws its masks from a counter-based hash of
+# (seed, step, site, element index) -- restated here so that the oracle can be run on exactly the masks the device used.
+#   site 1  flatten(h3) before h4_lin     rows = the 3B encoder images in the library's order [tgt | src | ctx]
+#   site 2  h4 before hz_lin              same rows
+#   site 3  concat([src_z, ctx_z])        B rows, 2 F columns
+#   site 4  trans_h0                      B rows
+#   site 5  z before d_h0_lin             rows = the 2B decoder passes [translated | truth]
+#   site 6  reshape(z_) before d_h1       same rows
+# Element index = row * (real, unpadded) columns + column.
+# --------------------------------------------------------------------------------------------------------------------
+def drop_hash(seed, step, site, n):
+    """u32 hash of element indices 0..n-1 (lowbias32 finaliser over a Weyl mix); numpy restatement of kernels.hip:drop_hash."""
+    M = np.uint64(0xFFFFFFFF)
+    x = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(site) * np.uint64(0x85EBCA77) +
+         np.uint64(step & 0xFFFFFFFF) * np.uint64(0xC2B2AE3D) + np.uint64(seed & 0xFFFFFFFF) * np.uint64(0x27D4EB2F)) & M
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M
+    x ^= x >> np.uint64(16)
+    return x.astype(np.uint32)
+
+
+def drop_masks(cfg, B, keep_prob, seed, step, dtype=np.float64):
+    """{site: mask / keep_prob, shaped [rows, real columns]} for one training step of batch B."""
+    h3, w3 = cfg.sizes[3]
+    D0, F = h3 * w3 * NF[3], cfg.featsize
+    thr = np.uint64(min(int(np.float32(keep_prob).astype(np.float64) * 4294967296.0), 4294967295))
+    shapes = {1: (3 * B, D0), 2: (3 * B, F), 3: (B, 2 * F), 4: (B, F), 5: (2 * B, F), 6: (2 * B, D0)}
+    inv = np.float32(1.0) / np.float32(keep_prob)           # the device multiplies by this f32 value
+    return {site: (drop_hash(seed, step, site, r * c).astype(np.uint64) < thr).reshape(r, c).astype(dtype) * dtype(inv)
+            for site, (r, c) in shapes.items()}
+
+
+def _encode(p, img, m1=None, m2=None):
+    """arm_shaping.py:1633-1640; m1 / m2: dropout factors (mask / keep_prob) of sites 1 and 2 for these images, or None."""
     acts, h = [], img
     for k in range(4):
         h = lrelu(conv2d(h, p[f"conv/h{k}_conv/w"], p[f"conv/h{k}_conv/biases"], s=NS[k]))
         acts.append(h)
-    h4 = lrelu(linear(h.reshape(h.shape[0], -1), p["conv/h4_lin/Matrix"], p["conv/h4_lin/bias"]))
-    z = lrelu(linear(h4, p["conv/hz_lin/Matrix"], p["conv/hz_lin/bias"]))
-    return acts + [h4, z]
+    flat = h.reshape(h.shape[0], -1)
+    x1 = flat if m1 is None else flat * m1
+    h4 = lrelu(linear(x1, p["conv/h4_lin/Matrix"], p["conv/h4_lin/bias"]))
+    x2 = h4 if m2 is None else h4 * m2
+    z = lrelu(linear(x2, p["conv/hz_lin/Matrix"], p["conv/hz_lin/bias"]))
+    return acts + [h4, z, x1, x2]
 
 
-def _decode(p, cfg, z, skips):
+def _decode(p, cfg, z, skips, m5=None, m6=None):
     """arm_shaping.py:1659-1672: d_h0_lin -> [-1, s_h3, s_w3, nf3]; deconvs with strides ns3, ns2, ns1, ns0
-    on concat([decoder, skip_h3 / h2 / h1 / h0], 3)."""
+    on concat([decoder, skip_h3 / h2 / h1 / h0], 3).  m5 / m6: dropout factors of sites 5 and 6 for this pass."""
     h3, w3 = cfg.sizes[3]
-    z_ = lrelu(linear(z, p["deconv/d_h0_lin/Matrix"], p["deconv/d_h0_lin/bias"]))
-    h = z_.reshape(-1, h3, w3, NF[3])
-    hs, cats = [z_], []
+    zin = z if m5 is None else z * m5
+    z_ = lrelu(linear(zin, p["deconv/d_h0_lin/Matrix"], p["deconv/d_h0_lin/bias"]))
+    h = (z_ if m6 is None else z_ * m6).reshape(-1, h3, w3, NF[3])
+    hs, cats = [z_], [zin]                      # cats[0] = what d_h0_lin was fed; cats[k] = the concat fed to d_hk
     out_sizes = [cfg.sizes[2], cfg.sizes[1], cfg.sizes[0], (cfg.H, cfg.W)]
     for k in range(1, 5):
         cat = np.concatenate([h, skips[4 - k]], axis=3)
@@ -114,16 +156,25 @@ def _decode(p, cfg, z, skips):
     return hs, cats
 
 
-def forward(p, src, ctx, tgt, cfg: RealConfig):
-    c = {"src": src, "ctx": ctx, "tgt": tgt}
-    c["e_src"], c["e_tgt"], c["e_ctx"] = _encode(p, src), _encode(p, tgt), _encode(p, ctx)     # :1642-1647
+def forward(p, src, ctx, tgt, cfg: RealConfig, drop=None):
+    """drop: None (keep_prob = 1, the sampler's and the validation graph) or the dict of drop_masks()."""
+    B = src.shape[0]
+    d = drop or {}
+    rows = {"tgt": slice(0, B), "src": slice(B, 2 * B), "ctx": slice(2 * B, 3 * B)}            # the library's encoder batch order
+    m = lambda site, sl: d[site][sl] if site in d else None
+    c = {"src": src, "ctx": ctx, "tgt": tgt, "drop": d}
+    c["e_src"] = _encode(p, src, m(1, rows["src"]), m(2, rows["src"]))                         # :1642-1647
+    c["e_tgt"] = _encode(p, tgt, m(1, rows["tgt"]), m(2, rows["tgt"]))
+    c["e_ctx"] = _encode(p, ctx, m(1, rows["ctx"]), m(2, rows["ctx"]))
     src_z, ctx_z, tgt_z = c["e_src"][5], c["e_ctx"][5], c["e_tgt"][5]
     c["tcat"] = np.concatenate([src_z, ctx_z], axis=1)
-    c["trans_h0"] = lrelu(linear(c["tcat"], p["translate/trans_h0/Matrix"], p["translate/trans_h0/bias"]))
-    c["trans_z"] = linear(c["trans_h0"], p["translate/trans_z/Matrix"], p["translate/trans_z/bias"])
+    c["tcat_d"] = c["tcat"] * d[3] if 3 in d else c["tcat"]
+    c["trans_h0"] = lrelu(linear(c["tcat_d"], p["translate/trans_h0/Matrix"], p["translate/trans_h0/bias"]))
+    c["trans_h0_d"] = c["trans_h0"] * d[4] if 4 in d else c["trans_h0"]
+    c["trans_z"] = linear(c["trans_h0_d"], p["translate/trans_z/Matrix"], p["translate/trans_z/bias"])
     skips = c["e_ctx"][:4]
-    c["d1"], c["d1_cats"] = _decode(p, cfg, c["trans_z"], skips)
-    c["d2"], c["d2_cats"] = _decode(p, cfg, tgt_z, skips)
+    c["d1"], c["d1_cats"] = _decode(p, cfg, c["trans_z"], skips, m(5, slice(0, B)), m(6, slice(0, B)))
+    c["d2"], c["d2_cats"] = _decode(p, cfg, tgt_z, skips, m(5, slice(B, 2 * B)), m(6, slice(B, 2 * B)))
     out, out2 = c["d1"][4], c["d2"][4]
     res = {"input_z": src_z, "translated_z": c["trans_z"], "out": out, "out2": out2,
            "simloss": np.mean((c["trans_z"] - tgt_z) ** 2) * 1e3,          # :1676
@@ -147,29 +198,34 @@ def backward(p, c, cfg: RealConfig, sim_batch=None):
         acc(f"{name}/bias", dy.sum(0))
         return dy @ p[f"{name}/Matrix"].T
 
-    def decode_bwd(hs, cats, dout):
+    d = c.get("drop", {})
+    mul = lambda x, site, sl: x * d[site][sl] if site in d else x          # the gradient of x * m is dy * m
+
+    def decode_bwd(hs, cats, dout, sl):
         dskips, dh = [None] * 4, dout
         for k in range(4, 0, -1):
             if k < 4:
                 dh = lrelu_grad(hs[k], dh)
-            dcat, dw, db = deconv2d_bwd(cats[k - 1], p[f"deconv/d_h{k}/w"], dh, s=NS[4 - k])
+            dcat, dw, db = deconv2d_bwd(cats[k], p[f"deconv/d_h{k}/w"], dh, s=NS[4 - k])
             acc(f"deconv/d_h{k}/w", dw)
             acc(f"deconv/d_h{k}/biases", db)
-            Cd = cats[k - 1].shape[3] // 2
+            Cd = cats[k].shape[3] // 2
             dskips[4 - k], dh = dcat[..., Cd:], dcat[..., :Cd]
-        return lrelu_grad(hs[0], dh.reshape(B, -1)), dskips
+        return lrelu_grad(hs[0], mul(dh.reshape(B, -1), 6, sl)), dskips
 
-    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] - tgt)
-    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] - tgt)
-    dtrans_z = lin_bwd("deconv/d_h0_lin", c["trans_z"], dz1_) + dsim
-    dtgt_z = lin_bwd("deconv/d_h0_lin", tgt_z, dz2_) - dsim
-    dth0 = lrelu_grad(c["trans_h0"], lin_bwd("translate/trans_z", c["trans_h0"], dtrans_z))
-    dtcat = lin_bwd("translate/trans_h0", c["tcat"], dth0)
+    p1, p2 = slice(0, B), slice(B, 2 * B)
+    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] - tgt, p1)
+    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] - tgt, p2)
+    dtrans_z = mul(lin_bwd("deconv/d_h0_lin", c["d1_cats"][0], dz1_), 5, p1) + dsim      # simloss sees the un-dropped codes
+    dtgt_z = mul(lin_bwd("deconv/d_h0_lin", c["d2_cats"][0], dz2_), 5, p2) - dsim
+    dth0 = lrelu_grad(c["trans_h0"], mul(lin_bwd("translate/trans_z", c["trans_h0_d"], dtrans_z), 4, slice(0, B)))
+    dtcat = mul(lin_bwd("translate/trans_h0", c["tcat_d"], dth0), 3, slice(0, B))
+    rows = {"tgt": slice(0, B), "src": slice(B, 2 * B), "ctx": slice(2 * B, 3 * B)}
 
-    def encode_bwd(img, acts, dz, dskips=None):
+    def encode_bwd(img, acts, dz, dskips=None, sl=None):
         dz = lrelu_grad(acts[5], dz)
-        dh4 = lrelu_grad(acts[4], lin_bwd("conv/hz_lin", acts[4], dz))
-        dh = lin_bwd("conv/h4_lin", acts[3].reshape(B, -1), dh4).reshape(acts[3].shape)
+        dh4 = lrelu_grad(acts[4], mul(lin_bwd("conv/hz_lin", acts[7], dz), 2, sl))
+        dh = mul(lin_bwd("conv/h4_lin", acts[6], dh4), 1, sl).reshape(acts[3].shape)
         for k in range(3, -1, -1):
             if dskips is not None:
                 dh = dh + dskips[k]
@@ -180,9 +236,9 @@ def backward(p, c, cfg: RealConfig, sim_batch=None):
             acc(f"conv/h{k}_conv/biases", db)
             dh = dx
 
-    encode_bwd(c["src"], c["e_src"], dtcat[:, :F])
-    encode_bwd(c["tgt"], c["e_tgt"], dtgt_z)
-    encode_bwd(c["ctx"], c["e_ctx"], dtcat[:, F:], dskips=[a + b for a, b in zip(dsk1, dsk2)])
+    encode_bwd(c["src"], c["e_src"], dtcat[:, :F], sl=rows["src"])
+    encode_bwd(c["tgt"], c["e_tgt"], dtgt_z, sl=rows["tgt"])
+    encode_bwd(c["ctx"], c["e_ctx"], dtcat[:, F:], dskips=[a + b for a, b in zip(dsk1, dsk2)], sl=rows["ctx"])
     return g
 
 

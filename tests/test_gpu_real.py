@@ -199,3 +199,34 @@ def test_real_split_bf16_mode_within_budget(T):
         c0 = np.broadcast_to(o.preprocess_u8(fr[1][0]), src.shape).astype(np.float64)
         tres, _ = r.forward(p, src.astype(np.float64), c0, c0, cfg)
         assert relmax(pred, tres["out"]) < 1e-4 and relmax(feat, tres["translated_z"]) < 1e-4
+
+
+@pytest.mark.parametrize("H,W,B,keep", [(36, 64, 3, 0.5), (16, 48, 2, 0.5), (12, 8, 4, 0.8)])
+def test_real_dropout_training_graph(T, H, W, B, keep):
+    """tf.nn.dropout at the six sites of ContextAEReal's training graph (arm_shaping.py:1637-1661; ablations_code/ablations.py:544
+    feeds keep_prob 0.5): with the masks of the step (a hash of seed / step / site / element that the oracle restates) the scalars
+    and every gradient equal the oracle's; the next step draws new masks; validation and the reward hook's fetches never drop
+    (ablations.py:556, the sampler's graph).  36x64 runs the narrow direct kernels, 16x48 / 12x8 the channel-padded path."""
+    cfg, p, fr = make(H, W, B, seed=3)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    f64 = [x.astype(np.float64) for x in (src, ctx, tgt)]
+    plain, _ = r.forward(p, *f64, cfg)
+    with T(H, W, featsize=100, max_batch=B, variant="real", keep_prob=keep) as tr:
+        tr.set_dropout_seed(11)
+        tr.set_params(p)
+        for step in range(2):
+            drop = r.drop_masks(cfg, B, keep, seed=11, step=step)
+            res, c = r.forward(p, *f64, cfg, drop)
+            g = r.backward(p, c, cfg)
+            assert abs(res["loss"] - plain["loss"]) > 1e-3 * plain["loss"]           # the masks do change the graph
+            sc = tr.train_step(src, ctx, tgt, lr=0.0)                                 # lr 0: parameters stay, the step counter moves on
+            for k in ("loss", "simloss", "recon1", "recon2"):
+                assert abs(sc[k] - res[k]) <= 2e-5 * abs(res[k]) + 1e-6, (step, k)
+            gg = tr.get_grads()
+            for n in g:
+                assert relmax(gg[n], g[n]) < 2e-4, (step, n)
+        ev = tr.evaluate(src, ctx, tgt)                                               # keep_prob = 1 outside training
+        assert abs(ev["loss"] - plain["loss"]) <= 1e-5 * plain["loss"] and relmax(ev["out"], plain["out"]) < 1e-5
+    from imitation_from_observation_amd import CtxError
+    with pytest.raises(CtxError, match="keep_prob"):
+        T(32, 32, 32, 128, max_batch=2, keep_prob=0.5)                                # ContextSkipNew has no dropout in its graph
