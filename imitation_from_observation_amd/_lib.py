@@ -79,6 +79,8 @@ SIGNATURES = {
     "ctx_encode": (_c.c_int, [_P, _U8, _c.c_int, _F, _F]),
     "ctx_translate_f32": (_c.c_int, [_P, _F, _F, _c.c_int, _c.c_int, _F, _F]),
     "ctx_encode_f32": (_c.c_int, [_P, _F, _c.c_int, _F]),
+    "ctx_translate_dev": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_int, _F, _F]),
+    "ctx_encode_dev": (_c.c_int, [_P, _P, _c.c_int, _F]),
     "ctx_reward_set_cache": (_c.c_int, [_P, _c.c_int, _F, _F, _c.c_int]),
     "ctx_reward_costs": (_c.c_int, [_P, _c.c_int, _U8, _c.c_int, _c.c_float, _c.c_int, _F]),
     "ctx_train_step": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _c.c_float, _F]),
@@ -116,6 +118,7 @@ SIGNATURES = {
     "ctx_cnn_last_error": (_c.c_char_p, [_P]),
     "ctx_cnn_set_weights": (_c.c_int, [_P, _F, _c.c_size_t]),
     "ctx_cnn_forward_u8": (_c.c_int, [_P, _U8, _c.c_int, _F]),
+    "ctx_cnn_forward_u8_dev": (_c.c_int, [_P, _U8, _c.c_int, _c.POINTER(_P)]),
     "ctx_cnn_forward_dev": (_c.c_int, [_P, _P, _c.c_int, _c.POINTER(_P)]),
     "ctx_cnn_read_buffer": (_c.c_int, [_P, _c.c_int, _c.c_int, _F]),
     "ctx_cnn_profile": (_c.c_int, [_P, _c.c_int, _c.c_int, _F, _c.c_int]),

@@ -310,6 +310,22 @@ int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out) {
     return CTX_OK;
 }
 
+// frames: host uint8 [n, H, W, 3], n <= max_images -> *d_out: DEVICE pointer of the last buffer [n, h, w, c].  Asynchronous on the
+// handle's stream (the upload is stream-ordered too; `frames` must stay valid until the stream has passed it -- callers that reuse
+// the buffer sync first).  The product path of mode 'oursinception': the feature maps never visit the host.
+int ctx_cnn_forward_u8_dev(ctx_cnn* h, const uint8_t* frames, int n, const float** d_out) {
+    if (!h || !frames || n <= 0 || n > h->max_images) return h ? cfail(h, CTX_E_INVALID, "n must be in [1, max_images]") : CTX_E_INVALID;
+    CNN_HIP(h, hipSetDevice(h->device));
+    const ctx_cnn_buf& b0 = h->bufs.front();
+    const int64_t pix_in = (int64_t)b0.h * b0.w;
+    CNN_HIP(h, hipMemcpyAsync(h->u8, frames, (size_t)n * pix_in * 3, hipMemcpyHostToDevice, h->stream));
+    pad_channels_u8(h->stream, h->u8, h->dbuf[0], n * pix_in, h->stem4 ? 4 : b0.c);
+    const int rc = run_cached(h, n);
+    if (rc != CTX_OK) return rc;
+    if (d_out) *d_out = h->dbuf.back();
+    return CTX_OK;
+}
+
 // d_frames: DEVICE f32 [n, H, W, 3] in [-1,1], n <= max_images; *d_out: device pointer of the last buffer [n, h, w, c].
 // Asynchronous on the handle's stream.
 int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** d_out) {

@@ -1213,6 +1213,35 @@ int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ct
     return translate_tail(h, B, pred, feat);
 }
 
+// The same two fetches with the inputs already on the DEVICE (the Inception front end's output buffer): results to the host.
+int ctx_translate_dev(ctx_handle* h, const float* d_src, const float* d_ctx0, int ctx_batched, int B, float* pred, float* feat) {
+    TRY(check_B(h, B));
+    if (!d_src || !d_ctx0) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int64_t npi = h->npi;
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, d_src, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    for (int slot = 0; slot <= 2; slot += 2) {             // image[1] = image[2] = [context]*B (base.py:217-218)
+        float* dst = h->img + (int64_t)slot * B * npi;
+        if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, d_ctx0, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        else
+            for (int b = 0; b < B; ++b)
+                HIP_TRY(h, hipMemcpyAsync(dst + (int64_t)b * npi, d_ctx0, (size_t)npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    return translate_tail(h, B, pred, feat);
+}
+
+int ctx_encode_dev(ctx_handle* h, const float* d_frames, int B, float* feat) {
+    TRY(check_B(h, B));
+    if (!d_frames) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_frames, (size_t)B * h->npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    TRY(forward_inference(h, B, MODE_ENCODE));
+    if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
+                                         hipMemcpyDeviceToHost, h->stream));
+    h->last_B = 0;
+    return finish(h);
+}
+
 int ctx_encode_f32(ctx_handle* h, const float* frames, int B, float* feat) {
     TRY(check_B(h, B));
     if (!frames) return fail(h, CTX_E_INVALID, "NULL input");

@@ -275,6 +275,23 @@ class InceptionFrontend:
                                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return out
 
+    def features_u8_dev(self, frames_u8):
+        """uint8 frames [n,H,W,3] (n <= max_images) -> integer DEVICE address of Mixed_7c [n,h,w,2048].  Asynchronous on the handle's
+        stream; the frames array is kept alive by this object until the next call / sync."""
+        fr = np.ascontiguousarray(frames_u8)
+        if fr.dtype != np.uint8 or fr.ndim != 4 or fr.shape[1:] != (self.H, self.W, 3):
+            raise ValueError(f"frames must be uint8 [n,{self.H},{self.W},3], got {fr.dtype} {fr.shape}")
+        self._pending = fr                                    # the upload reads it in stream order
+        d_out = ctypes.c_void_p()
+        self._ck(self._lib.ctx_cnn_forward_u8_dev(self._h, fr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), fr.shape[0], ctypes.byref(d_out)))
+        return d_out.value
+
+    def output(self, n):
+        """Host copy of the last forward's Mixed_7c maps [n,h,w,2048] (synchronises)."""
+        out = np.empty((n,) + tuple(self.out_shape), np.float32)
+        self._ck(self._lib.ctx_cnn_read_buffer(self._h, len(self._bufs) - 1, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        return out
+
     def features_dev(self, d_frames_f32, n):
         """Device f32 frames [n,H,W,3] in [-1,1] (integer address) -> integer device address of [n,h,w,2048].  Asynchronous."""
         d_out = ctypes.c_void_p()

@@ -91,7 +91,8 @@ class ModelTrainer:
         H, W = self.idims
         if self.inception:
             from .oursinception import InceptionTranslator
-            tr = InceptionTranslator((H, W), max_batch=self.batch_size, device=self.device, precision=self.precision)
+            tr = InceptionTranslator((H, W), max_batch=self.batch_size, device=self.device, precision=self.precision,
+                                     strides=self.strides, kernels=self.kernels, filters=self.filters)   # train_script.py:110
             tr.tr.init_params(self.seed)
             return tr
         variant = self.MODELS[self.model]
@@ -144,10 +145,9 @@ class ModelTrainer:
             src, ctx, tgt = self._batch(validdata, cs, ct)
             if resident:
                 ev = tr.eval_sampled(np.asarray(cs) + ntrain, np.asarray(ct) + ntrain)
-            elif self.inception:
-                f = tr.front.features(np.concatenate([src, ctx, tgt]))
-                src, ctx, tgt = f[:B], f[B:2 * B], f[2 * B:]
-                ev = tr.tr.evaluate(src, ctx, tgt)
+            elif self.inception:                               # feature maps stay on the device; nn_err compares with the tgt MAPS
+                ev = tr.evaluate_u8(src, ctx, tgt)
+                tgt = ev["tgt"]
             else:
                 ev = tr.evaluate(src, ctx, tgt)
             return ev, tgt

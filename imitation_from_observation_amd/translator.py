@@ -253,6 +253,19 @@ class Translator:
         self._ck(self._lib.ctx_translate_f32(self._h, _fp(src), _fp(ctx0), int(batched), B, _fp(pred), _fp(feat)))
         return pred, feat
 
+    def translate_dev(self, d_src, d_ctx0, B, ctx_batched=False):
+        """translate_f32 on DEVICE inputs (integer addresses of f32 [B,H,W,C] and [H,W,C] / [B,H,W,C]); host results."""
+        pred = np.empty((B, self.H, self.W, self.C), np.float32)
+        feat = np.empty((B, self.featsize), np.float32)
+        self._ck(self._lib.ctx_translate_dev(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx0), int(ctx_batched), B, _fp(pred), _fp(feat)))
+        return pred, feat
+
+    def encode_dev(self, d_frames, B):
+        """encode_f32 on a DEVICE input (integer address of f32 [B,H,W,C]); host result."""
+        feat = np.empty((B, self.featsize), np.float32)
+        self._ck(self._lib.ctx_encode_dev(self._h, ctypes.c_void_p(d_frames), B, _fp(feat)))
+        return feat
+
     def encode_f32(self, frames):
         """input_z of float inputs [B,H,W,C] (the `conv` encoder)."""
         fr = _f32(frames)

@@ -145,6 +145,11 @@ int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* 
 int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ctx_batched, int B,
                       float* pred, float* feat);
 int ctx_encode_f32(ctx_handle* h, const float* frames, int B, float* feat);
+/* ... and with the inputs already in DEVICE memory (d_*: f32 [B,H,W,C]; d_ctx0 [H,W,C] or, ctx_batched != 0, [B,H,W,C]), e.g. the
+ * output buffer of ctx_cnn_forward_u8_dev on the same stream: mode 'oursinception' without a host round trip of the feature maps
+ * (base.py:121-132, 216-218, 234-235).  pred / feat are HOST buffers (nullable). */
+int ctx_translate_dev(ctx_handle* h, const float* d_src, const float* d_ctx0, int ctx_batched, int B, float* pred, float* feat);
+int ctx_encode_dev(ctx_handle* h, const float* d_frames, int B, float* feat);
 
 /* The per-path cost of the reward hook computed where the frames already are (base.py:232-249), several paths per call:
  * ctx_reward_set_cache keeps, per viewpoint vp, the demo cache  means [bs, featsize] (= self.means[vp]) and  imgs [bs,H,W,3]
@@ -298,6 +303,9 @@ int ctx_cnn_set_weights(ctx_cnn* h, const float* blob, size_t n);
 /* frames: host uint8 [n,H,W,3], preprocessed like base.py:116-119; out: host f32 [n,h,w,c] of the last buffer.
  * n may exceed max_images (processed in chunks). */
 int ctx_cnn_forward_u8(ctx_cnn* h, const uint8_t* frames, int n, float* out);
+/* frames: host uint8 [n,H,W,3], n <= max_images; *d_out: DEVICE pointer of the last buffer [n,h,w,c] (valid until the next
+ * forward).  Asynchronous on the handle's stream: `frames` must stay untouched until the stream has passed the upload. */
+int ctx_cnn_forward_u8_dev(ctx_cnn* h, const uint8_t* frames, int n, const float** d_out);
 /* d_frames: DEVICE f32 [n,H,W,3] in [-1,1], n <= max_images; *d_out: device pointer of the last buffer.
  * Asynchronous on the handle's stream (ctx_cnn_stream / ctx_cnn_sync). */
 int ctx_cnn_forward_dev(ctx_cnn* h, const float* d_frames, int n, const float** d_out);

@@ -170,3 +170,41 @@ def test_three_channel_input_convs_any_kernel():
             assert not got[..., cout:].any()
     finally:
         lib.ctx_cnn_destroy(h)
+
+
+@pytest.mark.gpu
+def test_inception_translator_trains_without_host_feature_maps():
+    """mode 'oursinception' on the product path (scripts/train_script.py:98-114, 163, 176): uint8 frame triples -> frozen Inception-v3
+    -> ContextAEInception2 train step / validation fetch, the feature maps handed over as device pointers; scalars against the two
+    oracles composed on the CPU, for the sampler's lists and for another (strides, kernels, filters)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd.oursinception import InceptionTranslator
+    from oracle import ctx_oracle as o
+    from oracle import ctx_oracle_incep as oi
+    rng = np.random.default_rng(21)
+    B, S = 3, 125
+    frames = [rng.integers(0, 256, (B, S, S, 3), dtype=np.uint8) for _ in range(3)]
+    for lists in (None, dict(strides=[2, 1, 1, 1], kernels=[3, 1, 3, 3], filters=[64, 32, 32, 64])):
+        kw = lists or {}
+        with InceptionTranslator((S, S), max_batch=B, df_dim=4, **kw) as it:
+            ip = {k: v.astype(np.float64) for k, v in it.front.init_synthetic(4).items()}
+            cfg = oi.Incep2Config(H=2, W=2, C=2048, **({k: tuple(v) for k, v in lists.items()} if lists else dict(filters=(64, 64, 32, 32))))
+            tp = oi.init_params(cfg, 9, np.float32, stddev=0.01)
+            it.tr.set_params(tp)
+            f = [io.forward(ip, o.preprocess_u8(x).astype(np.float64))["Mixed_7c"] for x in frames]
+            res, _ = oi.forward({k: v.astype(np.float64) for k, v in tp.items()}, *f, cfg)
+            ev = it.evaluate_u8(*frames)
+            for k in ("loss", "simloss", "recon1", "recon2"):
+                assert abs(ev[k] - res[k]) <= 1e-3 * abs(res[k]) + 1e-6, k
+            assert np.abs(ev["out"] - res["out"]).max() <= 1e-3 * np.abs(res["out"]).max()
+            assert np.abs(ev["tgt"] - f[2]).max() <= 1e-3 * np.abs(f[2]).max()
+            l0 = it.train_step_u8(*frames, lr=1e-4)["loss"]
+            assert abs(l0 - res["loss"]) <= 1e-3 * abs(res["loss"])
+            for _ in range(3):
+                l1 = it.train_step_u8(*frames, lr=1e-4)["loss"]
+            assert l1 < l0
+            pred, feat = it.translate(frames[0], frames[1][0])
+            c0 = np.broadcast_to(f[1][0], f[0].shape)
+            assert pred.shape == (B, 2, 2, 2048) and feat.shape == (B, 1024)
