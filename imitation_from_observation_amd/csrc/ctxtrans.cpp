@@ -445,6 +445,7 @@ const char* const K_CONVT3D = "convt3_kernel";
 // the narrow-channel direct kernels of dconv.h (ContextSkipNew's 3-channel edge layers in f32, all of ContextAEReal's narrow path):
 // a launch group is labelled with the kernel that actually runs it
 const char* const K_WCONVT = "wconvt_kernel";       // wide-channel transposed conv with the input halo tile in LDS (wconvt.hip)
+const char* const K_C3CONV = "c3conv_kernel";       // conv from 3 channels, 4-wave blocks (c3conv.hip)
 const char* const K_DCFWD = "dconv_fwd_kernel";
 const char* const K_DCWGRAD = "dconv_wgrad_kernel";
 const char* const K_COLSUM = "colsum";
@@ -481,10 +482,12 @@ int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = ge
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
                 const float* b, float* y, int cb) {
     const int hs = hb / 2, ws = wb / 2, R = nimg * hs * ws;
-    ProfScope ps(h, name + " fwd", ca == 3 ? (use_dc3(h) ? K_DCFWD : K_C3FWD) : K_CONV, 2.0 * R * 25 * ca * cb);
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
-    if (ca == 3 && use_dc3(h)) {
+    const bool c3 = ca == 3 && use_dc3(h) && c3conv_ok(hb, wb, 2, cb, ep);
+    ProfScope ps(h, name + " fwd", ca == 3 ? (c3 ? K_C3CONV : use_dc3(h) ? K_DCFWD : K_C3FWD) : K_CONV, 2.0 * R * 25 * ca * cb);
+    if (c3) c3conv(h->stream, x, nimg, hb, wb, 2, w, cb, ep);
+    else if (ca == 3 && use_dc3(h)) {
         DcFwd P{};
         P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
         dconv_conv(h->stream, P, 2, 1);
@@ -681,7 +684,11 @@ void backward(ctx_handle* h, int B, int sim_batch) {
               Wg.big = dy; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dec_in; Wg.ld1 = c1; Wg.c1 = c1; Wg.s2 = h->c[4 - k]; Wg.ld2 = c2; Wg.nmod2 = B; Wg.CB = cb;
               Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = 2 * B; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
               dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats); }
-            { ProfScope ps(h, nm_ + " dx", K_DCFWD, fl);
+            if (c3conv_ok(hb, wb, 2, cb, ed)) {
+                ProfScope ps(h, nm_ + " dx", K_C3CONV, fl);
+                c3conv(h->stream, dy, 2 * B, hb, wb, 2, w, cb, ed);
+            } else {
+              ProfScope ps(h, nm_ + " dx", K_DCFWD, fl);
               DcFwd D{};
               D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack;
               dconv_conv(h->stream, D, 2, 1); }

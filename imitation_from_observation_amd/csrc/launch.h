@@ -52,6 +52,11 @@ void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_t
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   // filter gradient of either, 25 taps in one launch
 
+// conv2d 5x5 (stride 1 | 2, SAME) from a 3-channel tensor to N = 32 | 64 | 128 channels (c3conv.hip): h0_conv forward and the input
+// gradient of d_h4 in both models; epilogue = bias / lrelu / lrelu' mask / column split.  c3conv_ok: the shapes it is built for.
+bool c3conv_ok(int hin, int win, int stride, int N, const Epi& ep);
+void c3conv(hipStream_t s, const float* x, int nimg, int hin, int win, int stride, const float* w, int N, const Epi& ep);
+
 // conv2d_transpose 5x5 stride 2 for wide channel counts on the 8x8 / 16x16 grids: image-major, input halo tile resident in LDS
 // (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
 bool wconvt_ok(int hs, int ws, int c1, int c2, int ca);
