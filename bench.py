@@ -119,10 +119,7 @@ def secondary_legs(device, steps=40):
         h, w, c = front.out_shape
         tr = Translator(h, w, 64, 1024, max_batch=Bc, variant="inception2", C=c, precision="f32", stream=stream.cuda_stream, device=device)
         tr.init_params(1)
-        lay = 0.0
-        for op, cv in zip([o_ for o_ in front._ops if o_["kind"] == 0], front.convs):
-            ho, wo = front._bufs[op["dst"]][:2]
-            lay += 2.0 * ho * wo * cv["k"][0] * cv["k"][1] * cv["cin"] * cv["cout"]
+        lay = front.flops_per_image()
         per = h * w * c * 4
 
         def step():

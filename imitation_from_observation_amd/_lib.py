@@ -51,7 +51,8 @@ class CnnBuf(ctypes.Structure):
 
 class CnnOp(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("kind", "src", "dst", "dst_ch0", "kh", "kw", "stride", "same", "cout", "lane")] + \
-               [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)]
+               [("w_off", ctypes.c_int64), ("b_off", ctypes.c_int64)] + \
+               [(n, ctypes.c_int32) for n in ("src_ch0", "src_c", "nsplit", "dst2", "dst2_ch0", "reserved")]
 
 
 CTX_CNN_CONV, CTX_CNN_MAXPOOL, CTX_CNN_AVGPOOL = 0, 1, 2

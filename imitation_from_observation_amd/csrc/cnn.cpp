@@ -114,12 +114,22 @@ int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>
         if (op.kind != CTX_CNN_CONV) { o.kh = o.kw = 3; o.stride = op.kind == CTX_CNN_MAXPOOL ? 2 : 1; o.same = op.kind == CTX_CNN_AVGPOOL; }
         out_dims(in, o, ho, wo);
         if (ho != out.h || wo != out.w) return cfail(nullptr, CTX_E_INVALID, "op %zu: output grid %dx%d but buffer %d is %dx%d", i, ho, wo, op.dst, out.h, out.w);
-        const int cw = op.kind == CTX_CNN_CONV ? op.cout : in.c;
+        const int cw = op.kind == CTX_CNN_CONV ? (op.nsplit ? op.nsplit : op.cout) : in.c;
         if (op.dst_ch0 < 0 || op.dst_ch0 % 4 || op.dst_ch0 + cw > out.c) return cfail(nullptr, CTX_E_INVALID, "op %zu: channel slice [%d,%d) outside buffer %d", i, op.dst_ch0, op.dst_ch0 + cw, op.dst);
+        if (op.kind != CTX_CNN_CONV && (op.src_c || op.nsplit)) return cfail(nullptr, CTX_E_INVALID, "op %zu: channel slices / merged outputs are conv-only", i);
         if (op.kind == CTX_CNN_CONV) {
             if (op.kh < 1 || op.kw < 1 || op.kh * op.kw > 25 || op.cout <= 0 || op.cout % 4 || (op.stride != 1 && op.stride != 2))
                 return cfail(nullptr, CTX_E_INVALID, "op %zu: unsupported conv %dx%d stride %d cout %d", i, op.kh, op.kw, op.stride, op.cout);
-            const int64_t nw = (int64_t)op.kh * op.kw * in.c * op.cout;
+            if (op.src_c && (op.src_c % 32 || op.src_ch0 % 32 || op.src_ch0 < 0 || op.src_ch0 + op.src_c > in.c || op.src == 0))
+                return cfail(nullptr, CTX_E_INVALID, "op %zu: input slice [%d,%d) of buffer %d", i, op.src_ch0, op.src_ch0 + op.src_c, op.src);
+            if (op.nsplit) {
+                if (op.nsplit < 0 || op.nsplit % 4 || op.nsplit >= op.cout || op.dst2 < 0 || op.dst2 >= (int)bufs.size() || op.dst2 == op.src || op.dst2 == op.dst)
+                    return cfail(nullptr, CTX_E_INVALID, "op %zu: bad merged-output description", i);
+                const ctx_cnn_buf& o2 = bufs[op.dst2];
+                if (o2.h != out.h || o2.w != out.w || op.dst2_ch0 < 0 || op.dst2_ch0 % 4 || op.dst2_ch0 + (op.cout - op.nsplit) > o2.c)
+                    return cfail(nullptr, CTX_E_INVALID, "op %zu: second output slice outside buffer %d", i, op.dst2);
+            }
+            const int64_t nw = (int64_t)op.kh * op.kw * (op.src_c ? op.src_c : in.c) * op.cout;
             if (op.w_off < 0 || op.w_off % 4 || op.w_off + nw > weight_floats || op.b_off < 0 || op.b_off + op.cout > weight_floats)
                 return cfail(nullptr, CTX_E_INVALID, "op %zu: weights outside the blob", i);
         } else if (op.kind != CTX_CNN_MAXPOOL && op.kind != CTX_CNN_AVGPOOL) return cfail(nullptr, CTX_E_INVALID, "op %zu: unknown kind %d", i, op.kind);
@@ -145,7 +155,8 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
         if (par) for (int j : h->deps[oi]) (void)hipStreamWaitEvent(st, h->done[j], 0);
         const SplitWs ws{h->slab[L], h->slab_floats, h->precision};
         const ctx_cnn_buf &in = h->bufs[op.src], &out = h->bufs[op.dst];
-        const float* x = h->dbuf[op.src];
+        const float* x = h->dbuf[op.src] + (op.kind == CTX_CNN_CONV ? op.src_ch0 : 0);
+        const int cin = op.kind == CTX_CNN_CONV && op.src_c ? op.src_c : in.c;      // channels the conv reads (row stride stays in.c)
         float* y = h->dbuf[op.dst] + op.dst_ch0;
         if (op.kind == CTX_CNN_MAXPOOL) maxpool3x3s2(st, x, y, n, in.h, in.w, in.c, out.c);
         else if (op.kind == CTX_CNN_AVGPOOL) avgpool3x3s1(st, x, y, n, in.h, in.w, in.c, out.c);
@@ -154,6 +165,7 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
             const float* w = h->weights + op.w_off;
             Epi ep;
             ep.out1 = y; ep.ld1 = out.c; ep.bias = h->weights + op.b_off; ep.lrelu = 2;
+            if (op.nsplit) { ep.nsplit = op.nsplit; ep.out2 = h->dbuf[op.dst2] + op.dst2_ch0; ep.ld2 = h->bufs[op.dst2].c; }
             const int pady = op.same ? same_before(in.h, op.kh, op.stride) : 0, padx = op.same ? same_before(in.w, op.kw, op.stride) : 0;
             if (op.src == 0 && h->stem4) {
                 KmC3Gather a{x, in.h, in.w, out.h, out.w, R, h->zeros};
@@ -162,13 +174,13 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
                 b.ntap = op.kh * op.kw; b.cs = in.c;
                 conv3_fwd(st, a, b, ep, R, op.cout, ws);
             } else if (n >= 64 && op.same && op.kh * op.kw > 1) {   // position-major: SAME-padding taps outside the grid are never multiplied
-                PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, in.c / KC);
+                PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, cin / KC);
                 g.KW = op.kw; g.padx = padx;
-                conv_fwd_q(st, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, in.c, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
+                conv_fwd_q(st, KmConvGatherQ{x, in.c, g, n, h->zeros}, NmConvWeightsQ{w, cin, op.cout, op.kw, h->zeros}, ep, op.cout, ws);
             } else {
-                KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, in.c / KC, R, h->zeros};
+                KmConvGather a{x, in.c, in.h, in.w, out.h, out.w, cin / KC, R, h->zeros};
                 a.s = op.stride; a.K = op.kh; a.KW = op.kw; a.pad = pady; a.padx = padx;
-                NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * in.c, h->zeros};
+                NmPlain b{w, op.cout, nullptr, 0, op.cout, op.cout, op.kh * op.kw * cin, h->zeros};
                 conv_fwd(st, a, b, ep, R, op.cout, ws);
             }
         }
@@ -252,7 +264,7 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     for (int i = 0; i < nops && ok; ++i) {
         ok = hipEventCreateWithFlags(&h->done[i], hipEventDisableTiming) == hipSuccess;
         for (int j = 0; j < i; ++j)
-            if (vo[j].dst == vo[i].src && vo[j].lane != vo[i].lane) h->deps[i].push_back(j);
+            if ((vo[j].dst == vo[i].src || (vo[j].nsplit && vo[j].dst2 == vo[i].src)) && vo[j].lane != vo[i].lane) h->deps[i].push_back(j);
     }
     if (ok) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     // measured at 192 images of 125x125: branch lanes -11 % in the split-bf16 mode, +2 % (and a slower chained train step) in f32

@@ -81,9 +81,16 @@ def _pad32(c):
 
 
 class _Layout:
-    """Turns the table into buffers + ops.  A 'tensor' is (buffer id, h, w, real channels)."""
+    """Turns the table into buffers + ops.  A 'tensor' is (buffer id, h, w, real channels[, first channel inside the buffer]).
 
-    def __init__(self, H, W):
+    merge_heads: the 1x1 stride-1 convolutions that open several branches of a block all read the block's input; they are emitted
+    as ONE GEMM with their filters side by side along cout (Mixed_5b-5d 64+48+64, Mixed_6b-6e 192+c+c, Mixed_7a 192+192,
+    Mixed_7b/7c 320+384+448 -- nets/inception_v3.py:140-213, 236-364, 368-416): Branch_0's columns land in the block's concat
+    buffer, the others in channel slots of one temporary buffer that the branches' next convolutions read as slices.  The
+    variables keep their names, shapes and creation order; only their place in the weight blob changes (conv['ld'], ['col0'])."""
+
+    def __init__(self, H, W, merge_heads=True):
+        self.merge_heads = merge_heads
         self.bufs, self.ops, self.convs, self.endpoints = [], [], [], OrderedDict()
         self.woff = 0
         self.lane = 0                   # branch index inside a block: independent branches may overlap on the device
@@ -102,7 +109,7 @@ class _Layout:
 
     @staticmethod
     def out_grid(x, k, stride, padding):
-        _, h, w, _ = x
+        h, w = x[1], x[2]
         if padding == S:
             return -(-h // stride), -(-w // stride)
         return (h - k[0]) // stride + 1, (w - k[1]) // stride + 1
@@ -136,15 +143,19 @@ class _Layout:
             return (dst[0], h, w, c)
         if dst is None:
             dst = (self.new_buf(h, w, c)[0], 0)
-        src_c = self.bufs[x[0]][2]
+        sliced = len(x) > 4                                   # a channel slot of a merged-heads buffer
+        src_c = _pad32(x[3]) if sliced else self.bufs[x[0]][2]
         if step[0] == "conv":
             _, scope, cout, k, stride, padding = step
             nw = k[0] * k[1] * src_c * cout
             op = dict(kind=_lib.CTX_CNN_CONV, src=x[0], dst=dst[0], dst_ch0=dst[1], kh=k[0], kw=k[1], stride=stride, same=int(padding == S),
-                      cout=cout, w_off=self.woff, b_off=self.woff + nw, lane=self.lane)
-            self.convs.append(dict(scope=prefix + scope, k=k, cin=x[3], cin_pad=src_c, cout=cout, w_off=self.woff, b_off=self.woff + nw))
+                      cout=cout, w_off=self.woff, b_off=self.woff + nw, lane=self.lane,
+                      src_ch0=x[4] if sliced else 0, src_c=src_c if sliced else 0, nconvs=1)
+            self.convs.append(dict(scope=prefix + scope, k=k, cin=x[3], cin_pad=src_c, cout=cout, w_off=self.woff, b_off=self.woff + nw, grid=(h, w)))
             self.woff += (nw + cout + 3) // 4 * 4
         else:
+            if sliced:
+                raise ValueError("pools read whole buffers")
             if x[3] != src_c:
                 raise ValueError("pooling a channel-padded tensor into a slice would copy the padding")
             op = dict(kind=_lib.CTX_CNN_MAXPOOL if step[0] == "max" else _lib.CTX_CNN_AVGPOOL, src=x[0], dst=dst[0], dst_ch0=dst[1],
@@ -152,8 +163,10 @@ class _Layout:
         self.ops.append(op)
         return (dst[0], h, w, c)
 
-    def chain(self, x, chain, prefix, dst):
+    def chain(self, x, chain, prefix, dst, start=0):
         for i, st in enumerate(chain):
+            if i < start:
+                continue
             x = self.apply(x, st, prefix, dst if i == len(chain) - 1 else None)
         return x
 
@@ -161,11 +174,48 @@ class _Layout:
         shapes = [self.chain_shape(x, br) for br in branches]
         h, w = shapes[0][:2]
         out = self.new_buf(h, w, sum(s[2] for s in shapes))
-        off = 0
+        offs = [sum(s[2] for s in shapes[:bi]) for bi in range(len(branches))]
+        # ---- sibling 1x1 heads on the block input -> one GEMM
+        heads = [bi for bi, br in enumerate(branches) if br[0][0] == "conv" and br[0][3] == (1, 1) and br[0][4] == 1]
+        head_out, head_conv = {}, {}
+        if self.merge_heads and len(heads) >= 2:
+            src_c = self.bufs[x[0]][2]
+            direct = [bi for bi in heads if len(branches[bi]) == 1][:1]                    # lands in the concat buffer itself (Branch_0)
+            slotted = [bi for bi in heads if bi not in direct]
+            cols, col = {}, 0
+            for bi in direct:
+                cols[bi] = col
+                col += branches[bi][0][2]
+            nsplit = col
+            slot0 = col
+            for bi in slotted:
+                cols[bi] = col
+                col += _pad32(branches[bi][0][2])
+            ntot = col
+            tmp = self.new_buf(x[1], x[2], ntot - slot0) if slotted else None
+            nw = src_c * ntot
+            op = dict(kind=_lib.CTX_CNN_CONV, src=x[0], kh=1, kw=1, stride=1, same=1, cout=ntot, w_off=self.woff, b_off=self.woff + nw, lane=0,
+                      src_ch0=0, src_c=0, nconvs=len(heads), scopes=[f"{prefix}Branch_{bi}/" + branches[bi][0][1] for bi in heads])
+            if direct and slotted:
+                op.update(dst=out[0], dst_ch0=offs[direct[0]], nsplit=nsplit, dst2=tmp[0], dst2_ch0=0)
+            elif slotted:
+                op.update(dst=tmp[0], dst_ch0=0)
+            else:
+                op.update(dst=out[0], dst_ch0=offs[direct[0]])
+            self.ops.append(op)
+            for bi in heads:
+                cout = branches[bi][0][2]
+                head_conv[bi] = dict(scope=f"{prefix}Branch_{bi}/" + branches[bi][0][1], k=(1, 1), cin=x[3], cin_pad=src_c, cout=cout,
+                                     w_off=self.woff, b_off=self.woff + nw, ld=ntot, col0=cols[bi], grid=(x[1], x[2]))
+                head_out[bi] = (out[0], x[1], x[2], cout) if bi in direct else (tmp[0], x[1], x[2], cout, cols[bi] - slot0)
+            self.woff += (nw + ntot + 3) // 4 * 4
         for bi, (br, sh) in enumerate(zip(branches, shapes)):
             self.lane = bi % 4
-            self.chain(x, br, f"{prefix}Branch_{bi}/", (out[0], off))
-            off += sh[2]
+            if bi in head_out:
+                self.convs.append(head_conv[bi])                       # the variable inventory keeps the reference's creation order
+                self.chain(head_out[bi], br, f"{prefix}Branch_{bi}/", (out[0], offs[bi]), start=1)
+            else:
+                self.chain(x, br, f"{prefix}Branch_{bi}/", (out[0], offs[bi]))
         self.lane = 0
         return out
 
@@ -173,22 +223,26 @@ class _Layout:
 class InceptionFrontend:
     """frames -> Mixed_7c feature maps on one MI355X.  `max_images` bounds one device pass (larger batches are chunked)."""
 
-    def __init__(self, H=125, W=125, max_images=75, device=0, precision="f32", stream=None):
+    def __init__(self, H=125, W=125, max_images=75, device=0, precision="f32", stream=None, merge_heads=None):
         self._lib = _lib.load()
         self.H, self.W = H, W
-        lay = _Layout(H, W)
+        if merge_heads is None:
+            import os
+            merge_heads = os.environ.get("CTX_CNN_MERGE", "1") != "0"
+        lay = _Layout(H, W, merge_heads)
         # the output buffer must be the last one for the C side: re-number so that it is
         order = [i for i in range(len(lay.bufs)) if i != lay.out[0]] + [lay.out[0]]
         remap = {old: new for new, old in enumerate(order)}
         self._bufs = [lay.bufs[i] for i in order]
-        self._ops = [dict(op, src=remap[op["src"]], dst=remap[op["dst"]]) for op in lay.ops]
+        self._ops = [dict(op, src=remap[op["src"]], dst=remap[op["dst"]], dst2=remap[op["dst2"]] if op.get("nsplit") else 0) for op in lay.ops]
         self.convs, self.weight_floats = lay.convs, lay.woff
         self.endpoints = OrderedDict((k, (remap[v[0]],) + v[1:]) for k, v in lay.endpoints.items())
         self.out_shape = lay.out[1:]                       # (h, w, 2048)
         self.max_images = max_images
         bufs = (CnnBuf * len(self._bufs))(*[CnnBuf(*b) for b in self._bufs])
         ops = (CnnOp * len(self._ops))(*[CnnOp(o["kind"], o["src"], o["dst"], o["dst_ch0"], o["kh"], o["kw"], o["stride"], o["same"], o["cout"], o["lane"],
-                                               o["w_off"], o["b_off"]) for o in self._ops])
+                                               o["w_off"], o["b_off"], o.get("src_ch0", 0), o.get("src_c", 0), o.get("nsplit", 0), o.get("dst2", 0),
+                                               o.get("dst2_ch0", 0), 0) for o in self._ops])
         from .translator import Translator
         self._h = ctypes.c_void_p()
         rc = self._lib.ctx_cnn_create(bufs, len(self._bufs), ops, len(self._ops), self.weight_floats, max_images,
@@ -239,6 +293,11 @@ class InceptionFrontend:
             if w.shape != c["k"] + (c["cin"], c["cout"]):
                 raise ValueError(f"{c['scope']}/weights: expected {c['k'] + (c['cin'], c['cout'])}, got {w.shape}")
             scale = 1.0 / np.sqrt(var + BN_EPS)
+            if "ld" in c:                                     # a 1x1 head inside a merged filter [cin_pad][ld]: columns col0 .. col0 + cout
+                m = blob[c["w_off"]:c["w_off"] + c["cin_pad"] * c["ld"]].reshape(c["cin_pad"], c["ld"])
+                m[:c["cin"], c["col0"]:c["col0"] + c["cout"]] = (w * scale)[0, 0]
+                blob[c["b_off"] + c["col0"]:c["b_off"] + c["col0"] + c["cout"]] = beta - mean * scale
+                continue
             wp = np.zeros(c["k"] + (c["cin_pad"], c["cout"]))
             wp[:, :, :c["cin"], :] = w * scale
             blob[c["w_off"]:c["w_off"] + wp.size] = wp.reshape(-1)
@@ -275,6 +334,10 @@ class InceptionFrontend:
                                               out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
         return out
 
+    def flops_per_image(self):
+        """Algorithmic FLOPs of one image's pass (2 per multiply-add, real channel counts)."""
+        return float(sum(2.0 * c["grid"][0] * c["grid"][1] * c["k"][0] * c["k"][1] * c["cin"] * c["cout"] for c in self.convs))
+
     def features_u8_dev(self, frames_u8):
         """uint8 frames [n,H,W,3] (n <= max_images) -> integer DEVICE address of Mixed_7c [n,h,w,2048].  Asynchronous on the handle's
         stream; the frames array is kept alive by this object until the next call / sync."""
@@ -310,11 +373,17 @@ class InceptionFrontend:
         """[(scope or pool kind, kernel shape, output grid, ms)] per op for the n images of the last forward (measurement)."""
         ms = (ctypes.c_float * len(self._ops))()
         self._ck(self._lib.ctx_cnn_profile(self._h, n, iters, ms, len(self._ops)))
-        convs = iter(self.convs)
+        convs = iter([c for c in self.convs if "ld" not in c])
+        by_scope = {c["scope"]: c for c in self.convs}
         out = []
         for o, t in zip(self._ops, ms):
             h, w, _ = self._bufs[o["dst"]]
-            if o["kind"] == _lib.CTX_CNN_CONV:
+            if o["kind"] == _lib.CTX_CNN_CONV and o.get("nconvs", 1) > 1:                     # merged 1x1 heads of a block
+                cs = [by_scope[sc] for sc in o["scopes"]]
+                flops = sum(2.0 * n * h * w * c["cin"] * c["cout"] for c in cs)
+                out.append((cs[0]["scope"].rsplit("/", 2)[0] + "/{1x1 heads}", f"1x1 s1 SAME {cs[0]['cin']}->" + "+".join(str(c["cout"]) for c in cs),
+                            (h, w), float(t), flops))
+            elif o["kind"] == _lib.CTX_CNN_CONV:
                 c = next(convs)
                 flops = 2.0 * n * h * w * c["k"][0] * c["k"][1] * c["cin"] * c["cout"]
                 out.append((c["scope"], f"{c['k'][0]}x{c['k'][1]} s{o['stride']} {'SAME' if o['same'] else 'VALID'} {c['cin']}->{c['cout']}", (h, w), float(t), flops))

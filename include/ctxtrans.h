@@ -293,6 +293,14 @@ typedef struct ctx_cnn_op {
     int32_t lane;                     /* 0..3: ops of different lanes may run concurrently (the branches of an Inception block);
                                          the library orders every op after the writers of its src buffer */
     int64_t w_off, b_off;
+    /* ---- ABI 2 (zero-initialise for the plain forms) ----
+     * src_c != 0: the conv reads channels [src_ch0, src_ch0 + src_c) of buffer src (multiples of 32) instead of all of them: the
+     *   filter is then [kh][kw][src_c][cout].
+     * nsplit != 0 (CONV): a MERGED conv of sibling branches that read the same tensor (the 1x1 heads of an Inception block,
+     *   nets/inception_v3.py:140-213, 236-364, 389-416) -- one GEMM with the filters side by side along cout: output columns
+     *   [0, nsplit) go to (dst, dst_ch0), columns [nsplit, cout) to (dst2, dst2_ch0). */
+    int32_t src_ch0, src_c;
+    int32_t nsplit, dst2, dst2_ch0, reserved;
 } ctx_cnn_op;
 typedef struct ctx_cnn ctx_cnn;
 int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, int nops, int64_t weight_floats,

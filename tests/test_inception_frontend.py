@@ -10,7 +10,13 @@ from tests.test_oracle_inception import REF_SHAPES
 
 
 def test_layout_matches_reference_endpoints_and_variable_total():
-    lay = _Layout(299, 299)
+    for merge in (False, True):
+        _check_layout(_Layout(299, 299, merge))
+    assert len(_Layout(299, 299, True).ops) == 88 and len(_Layout(299, 299, False).ops) == 107   # 19 launches fewer with the 1x1 heads merged
+    assert _Layout(125, 125).out[1:] == (2, 2, 2048)
+
+
+def _check_layout(lay):
     assert list(lay.endpoints) == list(REF_SHAPES)
     for k, v in REF_SHAPES.items():
         assert lay.endpoints[k][1:] == v, k                                   # nets/inception_v3_test.py:87-104
@@ -21,13 +27,14 @@ def test_layout_matches_reference_endpoints_and_variable_total():
     # every concat is a set of adjacent, non-overlapping channel slices that tile the block output
     by_dst = {}
     for op in lay.ops:
-        width = op["cout"] if op["kind"] == 0 else lay.bufs[op["src"]][2]
+        width = (op.get("nsplit") or op["cout"]) if op["kind"] == 0 else lay.bufs[op["src"]][2]
         by_dst.setdefault(op["dst"], []).append((op["dst_ch0"], op["dst_ch0"] + width))
+        if op.get("nsplit"):
+            by_dst.setdefault(op["dst2"], []).append((op["dst2_ch0"], op["dst2_ch0"] + op["cout"] - op["nsplit"]))
     for name in ("Mixed_5b", "Mixed_6a", "Mixed_6e", "Mixed_7a", "Mixed_7c"):
         bid, _, _, c = lay.endpoints[name]
         sl = sorted(by_dst[bid])
         assert sl[0][0] == 0 and sl[-1][1] == c and all(a[1] == b[0] for a, b in zip(sl, sl[1:])), name
-    assert _Layout(125, 125).out[1:] == (2, 2, 2048)
 
 
 @pytest.fixture(scope="module")

@@ -24,10 +24,7 @@ for prec in ("f32", "bf16x3"):
     h, w, c = front.out_shape
     tr = Translator(h, w, 64, 1024, max_batch=B, variant="inception2", C=c, precision=prec, stream=stream.cuda_stream)
     tr.init_params(1)
-    lay_flops = 0
-    for op, cv in zip([o for o in front._ops if o["kind"] == 0], front.convs):
-        ho, wo = front._bufs[op["dst"]][:2]
-        lay_flops += 2.0 * ho * wo * cv["k"][0] * cv["k"][1] * cv["cin"] * cv["cout"]
+    lay_flops = front.flops_per_image()
     per = h * w * c * 4
 
     def step():
