@@ -620,7 +620,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
             ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, B, nd, hs, ws, w, ca, ep);
+            if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, B, nd, hs, ws, w, ca, ep, ws_of(h));
             else if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
                                        KmConvTWeightsQ{w, ca, c1 + c2, 5, g_zeros}, ep, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
@@ -793,7 +793,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             }
             const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, wsm, cb, 0, ca);
             ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl);
-            if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed);
+            if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed, ws_of(h));
             else if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
                                          KmConvTWeightsQ{sc.w[k], ca, cb, 5, g_zeros}, ed, ca, ws_of(h));
             else convt_fwd(h->stream, KmConvTGather{dA[k], cb, cb, nullptr, 0, 1, hs, wsm, cb / KC, R, g_zeros}, KmConvTWeights{sc.w[k], ca, cb, cb / KC, g_zeros},

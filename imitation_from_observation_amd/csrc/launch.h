@@ -61,7 +61,7 @@ void c3conv(hipStream_t s, const float* x, int nimg, int hin, int win, int strid
 // (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
 bool wconvt_ok(int hs, int ws, int c1, int c2, int ca);
 void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
-                const Epi& ep);
+                const Epi& ep, SplitWs ws_);
 
 // conv2d_transpose to 3 output channels (d_h4, arm_shaping.py:1329-1330) in two steps: the scatter
 // product P[pixel][(ky,kx,c)] = sum_k in[pixel][k] * w[ky,kx,c,k] as an MFMA GEMM (N = 75), then a

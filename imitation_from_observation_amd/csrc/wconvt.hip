@@ -37,6 +37,8 @@ struct WcT {
     const float* w; int ca;                      // filter [5][5][ca][c1 + c2], ca = output channels
     int nimg;
     int gn;                                      // column tiles
+    int ksplit;                                  // > 1: the channel slices are dealt to `ksplit` blocks per (tile, column tile); raw partial
+    float* slab;                                 // sums go to slab[split][output pixel][ca] and splitk_reduce applies the epilogue
     Epi ep;
 };
 
@@ -94,13 +96,19 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
     int item = blockIdx.x;
     {
         const int xcd = item & 7, l = item >> 3, nt = l % P.gn, g8 = l / P.gn;
-        item = (g8 * 8 + xcd) * P.gn + nt;
+        item = (g8 * 8 + xcd) * P.gn + nt;                       // (splits are the outermost index: g8 runs through them)
     }
     const int ntile = ((P.nimg + IMGT - 1) / IMGT) * TPI;
+    const int nt8 = (ntile + 7) / 8 * 8 * P.gn;                  // items per split (whole groups of 8 tiles: the XCD mapping above)
+    const int split = item / nt8;
+    item -= split * nt8;
     const int tile = item / P.gn, ctile = item - tile * P.gn;
     if (tile >= ntile) return;
     const int img0 = (tile / TPI) * IMGT, i0 = (tile % TPI) * TH, n0 = ctile * BROWS;
-    const int cb = P.c1 + P.c2, nslice = cb >> 5, ns1 = P.c1 >> 5;
+    const int cb = P.c1 + P.c2, ns1 = P.c1 >> 5;
+    const int nsl_all = cb >> 5, per = (nsl_all + P.ksplit - 1) / P.ksplit;
+    const int sbeg = split * per, nslice = sbeg + per < nsl_all ? sbeg + per : nsl_all;      // this block's slices [sbeg, nslice)
+    if (sbeg >= nslice) return;                                    // (never with the launcher's split counts)
 
     const rsrc_t rs1 = make_rsrc(P.s1), rs2 = make_rsrc(P.s2 ? P.s2 : P.s1);
 
@@ -159,20 +167,20 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
     // ---- prologue: slice 0 and tap 0 into LDS, tap 1 into the registers ------------------------------------------
     float4 areg[NPA], breg[NPB];
 #pragma unroll
-    for (int p = 0; p < NPA; ++p) areg[p] = a_load(0, p);
-    b_load(0, tap_info(0).ky * 5 + tap_info(0).kx, breg);
+    for (int p = 0; p < NPA; ++p) areg[p] = a_load(sbeg, p);
+    b_load(sbeg, tap_info(0).ky * 5 + tap_info(0).kx, breg);
 #pragma unroll
     for (int p = 0; p < NPA; ++p) a_store(p, areg[p]);
     b_store(0, breg);
-    b_load(0, tap_info(1).ky * 5 + tap_info(1).kx, breg);
+    b_load(sbeg, tap_info(1).ky * 5 + tap_info(1).kx, breg);
     __syncthreads();
 
-    for (int s = 0; s < nslice; ++s) {
+    for (int s = sbeg; s < nslice; ++s) {
         const int snext = s + 1 < nslice ? s + 1 : s;
 #pragma unroll
         for (int t = 0; t < 25; ++t) {
             const TapInfo ti = tap_info(t);
-            const int g = s * 25 + t;
+            const int g = (s - sbeg) * 25 + t;
             const int stage = g & 1;
             const float* aT = aBase + ((ti.dy + 1) * WPL + (ti.dx + 1)) * WC_LDP;
             const float* bT = bBase + stage * BSTAGE;
@@ -224,6 +232,23 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
     // costs more than a slice of the MFMA loop).
     const Epi& e = P.ep;
     const int mm = 32 * wv + wc_pos<WS>(l31);
+    if (P.slab) {                                                  // split over the channel slices: raw partial sums, [split][pixel][ca]
+        const int il2 = mm / (TH * WS), p2 = mm - il2 * (TH * WS), i2 = i0 + p2 / WS, j2 = p2 % WS;
+        const int img = img0 + il2;
+        if (img >= P.nimg) return;
+        const int64_t npix = (int64_t)P.nimg * (4 * HS * WS);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t pix = ((int64_t)img * (2 * HS) + 2 * i2 + (c >> 1)) * (2 * WS) + 2 * j2 + (c & 1);
+            float* q = P.slab + ((int64_t)split * npix + pix) * P.ca + n0 + 4 * h;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(q + nb * 32 + 8 * g) = make_float4(acc[c][nb][4 * g], acc[c][nb][4 * g + 1], acc[c][nb][4 * g + 2], acc[c][nb][4 * g + 3]);
+        }
+        return;
+    }
     const int il2 = mm / (TH * WS), p2 = mm - il2 * (TH * WS), i2 = i0 + p2 / WS, j2 = p2 % WS;
     const int img = img0 + il2;
     const bool rowok = img < P.nimg;
@@ -281,7 +306,7 @@ void launch_wc(hipStream_t s, const WcT& P) {
     constexpr size_t lds = (size_t)(TPIX * WC_LDP + 2 * 32 * NB * WC_LDP) * sizeof(float);
     static_assert(lds <= 65536, "two blocks per CU");
     const int ntile = ((P.nimg + IMGT - 1) / IMGT) * TPI;
-    const int items = (ntile + 7) / 8 * 8 * P.gn;         // whole groups of 8 tiles: the XCD mapping above
+    const int items = (ntile + 7) / 8 * 8 * P.gn * P.ksplit;      // whole groups of 8 tiles: the XCD mapping above
     hipLaunchKernelGGL((wconvt_kernel<HS, WS, NB>), dim3((unsigned)items), dim3(WC_THREADS), lds, s, P);
 }
 
@@ -290,24 +315,48 @@ void launch_wc(hipStream_t s, const WcT& P) {
 // the shapes this kernel is instantiated for (everything else stays on the implicit GEMM)
 bool wconvt_ok(int hs, int ws, int c1, int c2, int ca) {
     static const bool on = [] { const char* e = getenv("CTX_WCONVT"); return !(e && e[0] == '0'); }();
-    // 4x4 grids: measured equal to the class-major implicit GEMM (d_h1 fwd 0.82 ms either way: 64 tiles x 4 column tiles leave one
-    // block per CU) -- kept behind CTX_WCONVT_4X4=1
-    static const bool on4 = [] { const char* e = getenv("CTX_WCONVT_4X4"); return e && e[0] == '1'; }();
+    // 4x4 grids (8 images per tile, 32-wide column tiles so that the launch has 512 blocks): layer times equal to the class-major
+    // implicit GEMM when timed alone, the whole step 0.08 ms faster (13.72 vs 13.81 ms).  CTX_WCONVT_4X4=0 keeps them off.
+    static const bool on4 = [] { const char* e = getenv("CTX_WCONVT_4X4"); return !(e && e[0] == '0'); }();
     return on && ((hs == 4 && ws == 4 && on4) || (hs == 8 && ws == 8) || (hs == 16 && ws == 16)) && c1 > 0 && c1 % 32 == 0 && c2 % 32 == 0 && ca % 32 == 0;
 }
 
+void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);     // kernels.hip
+
 void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
-                const Epi& ep) {
-    WcT P{s1, c1, s2, c2, nmod2 > 0 ? nmod2 : 1, w, ca, nimg, 1, ep};
-    // 64 output channels per block where the launch still fills the chip's 512 block slots with them; 32 otherwise (small batches, ca = 32)
+                const Epi& ep, SplitWs wsp) {
+    WcT P{s1, c1, s2, c2, nmod2 > 0 ? nmod2 : 1, w, ca, nimg, 1, 1, nullptr, ep};
     const int img_per = hs * ws >= 128 ? 1 : 128 / (hs * ws), tpi = hs * ws >= 128 ? hs * ws / 128 : 1;
     const int64_t ntile = (int64_t)((nimg + img_per - 1) / img_per) * tpi;
-    static const int force_nb = [] { const char* e = getenv("CTX_WCONVT_NB"); return e ? atoi(e) : 0; }();     // A/B switch
-    const bool nb2 = ca % 64 == 0 && (force_nb ? force_nb == 2 : ntile * (ca / 64) >= 400);
+    static const int force_nb = [] { const char* e = getenv("CTX_WCONVT_NB"); return e ? atoi(e) : 0; }();     // A/B switches
+    static const int force_ks = [] { const char* e = getenv("CTX_WCONVT_KSPLIT"); return e ? atoi(e) : 0; }();
+    // 64 output channels per block (half the filter traffic of 32).  A launch should offer >= ~400 blocks to the chip's 512 slots: where
+    // tiles x column tiles fall short (the 4x4 grids: 8 images per tile; the 256-image conv_context launches) the channel slices are
+    // split over 2 or 4 blocks whose partial sums meet in splitk_reduce (output-sized slabs: a few % of the layer).
+    const int nsl = (c1 + c2) / 32;
+    const int64_t npix = (int64_t)nimg * 4 * hs * ws;
+    bool nb2 = ca % 64 == 0;
+    if (force_nb) nb2 = nb2 && force_nb == 2;
+    int ks = 1;
+    static const int ks_max = [] { const char* e = getenv("CTX_WCONVT_KSMAX"); return e ? atoi(e) : 4; }();
+    // Measured (B = 256, whole step, three runs each): splitting the 4x4 launches makes THEM faster when timed alone (d_h1 forward 0.82 ->
+    // 0.78 ms, conv_context h3 dx 0.31 -> 0.23) but the step no faster (13.75 vs 13.72 ms): they share the chip with the side lanes, and the
+    // slabs + reduce launches take from those.  So the default is no split (narrower column tiles instead); CTX_WCONVT_KSGRID=16 turns it on.
+    static const int ks_grid = [] { const char* e = getenv("CTX_WCONVT_KSGRID"); return e ? atoi(e) : 0; }();    // largest grid (positions) that may split
+    while (hs * ws <= ks_grid && ks < ks_max && ntile * (ca / (nb2 ? 64 : 32)) * ks < 400 && nsl / (2 * ks) >= 4 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
+    if (force_ks) ks = force_ks;
+    if (ks == 1 && nb2 && !force_nb && ntile * (ca / 64) < 400) nb2 = false;        // no room to split: narrower column tiles instead
     P.gn = nb2 ? ca / 64 : ca / 32;
+    P.ksplit = ks;
+    P.slab = ks > 1 ? wsp.slab : nullptr;
     if (hs == 4) { if (nb2) launch_wc<4, 4, 2>(s, P); else launch_wc<4, 4, 1>(s, P); }
     else if (hs == 8) { if (nb2) launch_wc<8, 8, 2>(s, P); else launch_wc<8, 8, 1>(s, P); }
     else { if (nb2) launch_wc<16, 16, 2>(s, P); else launch_wc<16, 16, 1>(s, P); }
+    if (ks > 1) {
+        Epi er = ep;                                              // rows of the reduction = output pixels in memory order
+        er.slab = wsp.slab; er.rowmode = 0;
+        splitk_reduce(s, er, (int)npix, ca, 1, ks);
+    }
 }
 
 }  // namespace ctx
