@@ -240,7 +240,7 @@ void launch_ct3(hipStream_t s, Ct3 A, int TW) {
     A.tiles_x = (A.win + A.TW - 1) / A.TW;
     A.ntiles = A.nimg * A.tiles_y * A.tiles_x;
     const size_t lds = (size_t)((A.IH * A.IW * PS + 3) & ~3) * 4 + 25 * 4 * KS * 4;
-    if (A.IH * A.IW * KQ > NT * CT3_PF || lds > 160 * 1024) { fprintf(stderr, "convt3: tile %d x %d does not fit\n", A.IH, A.IW); abort(); }
+    if (A.IH * A.IW * KQ > NT * CT3_PF || lds > 160 * 1024) { set_launch_error("convt3: input tile %d x %d does not fit the prefetch slots / LDS", A.IH, A.IW); return; }
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute((const void*)convt3_kernel<S, P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
     int per_cu = (int)((160 * 1024) / (lds + 1024));

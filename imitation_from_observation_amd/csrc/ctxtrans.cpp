@@ -873,6 +873,7 @@ int copy_d2h(ctx_handle* h, void* dst, const void* src, size_t bytes) {
 }
 
 int finish(ctx_handle* h) {
+    { char msg[256]; if (take_launch_error(msg, sizeof msg)) return fail(h, CTX_E_DEVICE, "%s", msg); }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return CTX_OK;

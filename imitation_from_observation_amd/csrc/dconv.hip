@@ -116,7 +116,7 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
                     if (score > best) { best = score; best_th = th; best_mi = mi; best_tw = tw; best_nb = nb; best_occ = occ; }
                 }
     }
-    if (!best_th) { fprintf(stderr, "dconv: no tile fits (CI %d N %d)\n", P.CI, P.N); return; }
+    if (!best_th) { set_launch_error("dconv: no tile fits LDS for CI %d, N %d", P.CI, P.N); return; }
     if (g_dc_force[0]) {
         best_th = g_dc_force[0]; best_tw = g_dc_force[1]; best_mi = g_dc_force[2];
         const int ih = P.S * (best_th - 1) + span, iw = P.S * (best_tw - 1) + span;

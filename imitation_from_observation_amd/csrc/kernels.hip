@@ -1,8 +1,25 @@
 // kernels.hip -- the HBM-bound and small kernels around the implicit GEMMs: split-K combine,
 // conv2d_transpose to 3 channels, input preprocessing, losses, bias gradients, lrelu', Adam.
+#include <cstdarg>
+#include <cstdio>
 #include "launch.h"
 
 namespace ctx {
+
+namespace { thread_local char g_launch_err[256]; thread_local bool g_launch_err_set = false; }
+void set_launch_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_launch_err, sizeof g_launch_err, fmt, ap);
+    va_end(ap);
+    g_launch_err_set = true;
+}
+bool take_launch_error(char* buf, size_t n) {
+    if (!g_launch_err_set) return false;
+    snprintf(buf, n, "%s", g_launch_err);
+    g_launch_err_set = false;
+    return true;
+}
 
 // ------------------------------------------------------------------------------------------------
 // split-K: out = epilogue(sum_s slab[s]); fixed summation order => deterministic
