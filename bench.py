@@ -91,13 +91,11 @@ def secondary_legs(device, steps=40):
              for _ in range(3)]
         torch.cuda.synchronize()
         for _ in range(5):
-            tr.dev_forward_backward(*(t.data_ptr() for t in d), Bb)
-            tr.dev_adam(1e-4)
+            tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
         tr.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
-            tr.dev_forward_backward(*(t.data_ptr() for t in d), Bb)
-            tr.dev_adam(1e-4)
+            tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
         tr.sync()
         dt = (time.perf_counter() - t0) / steps
         fl = real_flops_per_triple(Hh, Ww) * Bb
@@ -124,8 +122,7 @@ def secondary_legs(device, steps=40):
 
         def step():
             dd = front.features_dev(frames.data_ptr(), 3 * Bc)
-            tr.dev_forward_backward(dd, dd + Bc * per, dd + 2 * Bc * per, Bc)
-            tr.dev_adam(1e-4)
+            tr.dev_train_step(dd, dd + Bc * per, dd + 2 * Bc * per, Bc, 1e-4)
 
         for _ in range(3):
             step()

@@ -94,6 +94,7 @@ SIGNATURES = {
     "ctx_eval": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _F, _F, _F]),
     "ctx_dev_forward_backward": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int]),
     "ctx_dev_forward": (_c.c_int, [_P, _P, _P, _P, _c.c_int]),
+    "ctx_dev_train_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float]),
     "ctx_set_grad_bucket_callback": (_c.c_int, [_P, _P, _P]),
     "ctx_dev_adam": (_c.c_int, [_P, _c.c_float]),
     "ctx_dev_scalars": (_c.c_int, [_P, _F]),

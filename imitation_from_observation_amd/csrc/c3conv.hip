@@ -12,7 +12,12 @@
 //     are the three channels -- the zero fourth channel of the [pixel][4] LDS image is never multiplied (21 MFMAs per 16 x 16
 //     block instead of 25: 12 % over the 18.75 a dense K would need, was 33 %);
 //   * tap offsets are literals: a chunk's A fragment is one ds_read_b128 at (per-lane-group) precomputed byte offsets;
-//   * products are formed transposed (rows = output channels), so every store / epilogue load is one float4 per lane.
+//   * products are formed transposed (rows = output channels), so every store / epilogue load is one float4 per lane;
+//   * nothing in the epilogue waits on vmcnt between stores: the bias sits in LDS, the lrelu' mask rows of a tile are loaded in
+//     one batch before its first store (the first version loaded the bias per 16-column block, and the s_waitcnt vmcnt(0) in
+//     front of each use also waited for the PREVIOUS block's stores -- 8 to 16 store round trips per tile, matrix pipe 42 % busy);
+//   * the prefetch addresses are branch-free: per thread and slot the in-tile byte offset and column are packed once, rows outside
+//     the frame fall outside the per-frame buffer descriptor by themselves, only the column test remains.
 // v_mfma_f32_16x16x4_f32, exact f32.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -45,6 +50,7 @@ __global__ __launch_bounds__(C3_THREADS, (NB <= 4 ? 3 : 2)) void c3conv_kernel(c
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tile = smem;                                       // [IH * IW][4]
     float* W4 = smem + ((IH * IW * 4 + 3) & ~3);              // [C3_NCH * 4 slots][N][4]
+    float* Bs = W4 + C3_NCH * 4 * N * 4;                      // [N] bias (zeros without one)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l15 = lane & 15, kg = lane >> 4;
 
@@ -56,6 +62,7 @@ __global__ __launch_bounds__(C3_THREADS, (NB <= 4 ? 3 : 2)) void c3conv_kernel(c
         *reinterpret_cast<float4*>(&W4[(size_t)i * 4]) = v;
     }
     for (int i = tid; i < IH * IW; i += C3_THREADS) tile[i * 4 + 3] = 0.f;    // the fourth channel: written once, never loaded
+    for (int i = tid; i < N; i += C3_THREADS) Bs[i] = P.ep.bias ? P.ep.bias[i] : 0.f;
 
     // ---- input tile prefetch: float e = tid + 256 j of the tile's IH rows of IW * 3 contiguous floats
     unsigned pf[C3_PF];
@@ -64,17 +71,26 @@ __global__ __launch_bounds__(C3_THREADS, (NB <= 4 ? 3 : 2)) void c3conv_kernel(c
         const int tyi = t % P.tiles_y;
         img = t / P.tiles_y; y0 = tyi * TH; x0 = txi * TW;
     };
+    // slot j of this thread: float e = tid + 256 j of the tile = row r, float c of the row, walked incrementally from slot 0
+    // (256 = RQ rows + RR floats); slots past the tile (e >= TFL) read some float of the tile again and are never landed
+    constexpr int RD = IW * 3, RQ = C3_THREADS / RD, RR = C3_THREADS % RD;
+    const int r0 = tid / RD, c0 = tid - r0 * RD;
+    const unsigned frame_bytes = (unsigned)(P.hin * P.win * 3 * 4), win3 = (unsigned)(P.win * 3);
     auto issue = [&](int t) {
         int img, y0, x0;
         tile_org(t, img, y0, x0);
-        const rsrc_t rs = make_rsrc(P.x + (int64_t)img * P.hin * P.win * 3);
-        const int iy0 = S * y0 - PAD, ix0 = (S * x0 - PAD) * 3;
+        // num_records = one frame: rows above / below it (negative or too large offsets) read as zeros by themselves
+        const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x + (int64_t)img * P.hin * P.win * 3), 0, (int)frame_bytes, 0x00020000);
+        const int ix0 = (S * x0 - PAD) * 3;
+        unsigned roff = (unsigned)((((S * y0 - PAD) + r0) * (int)win3 + ix0) * 4);      // byte offset of (row, float 0 of the tile row)
+        int c = c0;
 #pragma unroll
         for (int j = 0; j < C3_PF; ++j) {
-            const int e = tid + C3_THREADS * j, r = e / (IW * 3), c = e - r * (IW * 3);
-            const int gy = iy0 + r, gx3 = ix0 + c;
-            const bool ok = e < TFL && (unsigned)gy < (unsigned)P.hin && (unsigned)gx3 < (unsigned)(P.win * 3);
-            pf[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (uint32_t)((gy * P.win * 3 + gx3) * 4) : OOB, 0, 0);
+            const unsigned gx3 = (unsigned)(ix0 + c);
+            pf[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, gx3 < win3 ? roff + 4u * (unsigned)c : OOB, 0, 0);
+            c += RR; roff += (unsigned)RQ * win3 * 4u;
+            const bool wrap = c >= RD;
+            c = wrap ? c - RD : c; roff = wrap ? roff + win3 * 4u : roff;
         }
     };
     auto land = [&]() {
@@ -110,72 +126,91 @@ __global__ __launch_bounds__(C3_THREADS, (NB <= 4 ? 3 : 2)) void c3conv_kernel(c
         __syncthreads();                                       // tile (first pass: and the filter) visible
         if (t + (int)gridDim.x < P.ntiles) issue(t + gridDim.x);
 
-        f32x4 acc[2][NB];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 a[2][2], b[2][NB];
-        auto fetch = [&](int j, int buf) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) a[buf][m] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tile) + abase[m] + toff[j]);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) b[buf][nb] = *reinterpret_cast<const float4*>(bbase + (size_t)j * (4 * N * 16) + nb * 256);
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int j = 0; j < C3_NCH; ++j) {
-            if (j + 1 < C3_NCH) fetch(j + 1, (j + 1) & 1);
-#pragma unroll
-            for (int tt = 0; tt < 3; ++tt)                      // the three channels; the zero fourth one is skipped
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const float4 av4 = a[j & 1][m];
-                    const float av = tt == 0 ? av4.x : tt == 1 ? av4.y : av4.z;
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const float4 bv4 = b[j & 1][nb];
-                        const float bv = tt == 0 ? bv4.x : tt == 1 ? bv4.y : bv4.z;
-                        acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[m][nb], 0, 0, 0);   // D^T: rows = channels, cols = pixels
-                    }
-                }
-        }
-
-        // ---- epilogue: a lane holds channels 16 nb + 4 kg .. + 3 of pixel l15 of each of its two row blocks
+        // output pixels of this lane's two row blocks
         int img, y0, x0;
         tile_org(t, img, y0, x0);
+        int pix[2];                                              // (32-bit element offsets: every activation tensor of a handle is < 2 GiB, ctx_create)
+        bool okm[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int rb = 2 * wv + m, ty = rb / TWB, tx = rb - ty * TWB;
             const int y = y0 + ty, x = x0 + 16 * tx + l15;
-            const bool ok = y < P.hout && x < P.wout;
-            const int64_t pix = ok ? ((int64_t)img * P.hout + y) * P.wout + x : 0;       // (a pixel that exists)
-            float4 tm[NB];
-            if (P.ep.mask) {
+            okm[m] = y < P.hout && x < P.wout;
+            pix[m] = okm[m] ? (img * P.hout + y) * P.wout + x : 0;                       // (a pixel that exists)
+        }
+
+        // The columns go in passes of NP <= 4 blocks of 16 (N = 128: two passes over the same LDS tile): 32 accumulator registers
+        // instead of 64, and a pass's lrelu' mask rows are requested BEFORE its MFMA loop when there are two passes
+        constexpr int NP = NB > 4 ? 4 : NB, NPASS = NB / NP;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int n = 16 * nb + 4 * kg;
-                    tm[nb] = ldg4(P.ep.mask + pix * P.ep.ldm + (n < P.ep.nsplit ? n : 0));
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const bool masked = P.ep.mask && 16 * NP * ps < P.ep.nsplit;
+            float4 tm[2][NP];
+            auto fetch_mask = [&]() {
+                if (masked) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const int n = 16 * (NP * ps + q) + 4 * kg;
+                            tm[m][q] = ldg4(P.ep.mask + (unsigned)(pix[m] * (int)P.ep.ldm + (n < P.ep.nsplit ? n : 0)));
+                        }
                 }
-            }
-            if (!ok) continue;
+            };
+            if (NPASS > 1) fetch_mask();
+
+            f32x4 acc[2][NP];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int n = 16 * nb + 4 * kg;
-                float v[4] = {acc[m][nb][0], acc[m][nb][1], acc[m][nb][2], acc[m][nb][3]};
-                if (P.ep.bias) { const float4 bb = ldg4(P.ep.bias + n); v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w; }
-                if (P.ep.lrelu) {
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], leak * v[r]);
-                }
-                if (n < P.ep.nsplit) {
-                    if (P.ep.mask) {
-                        v[0] *= tm[nb].x >= 0.f ? 1.f : LEAK; v[1] *= tm[nb].y >= 0.f ? 1.f : LEAK;
-                        v[2] *= tm[nb].z >= 0.f ? 1.f : LEAK; v[3] *= tm[nb].w >= 0.f ? 1.f : LEAK;
+                for (int q = 0; q < NP; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float4 a[2][2], b[2][NP];
+            auto fetch = [&](int j, int buf) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) a[buf][m] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(tile) + abase[m] + toff[j]);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b[buf][q] = *reinterpret_cast<const float4*>(bbase + (size_t)j * (4 * N * 16) + (NP * ps + q) * 256);
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int j = 0; j < C3_NCH; ++j) {
+                if (j + 1 < C3_NCH) fetch(j + 1, (j + 1) & 1);
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)                      // the three channels; the zero fourth one is skipped
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const float4 av4 = a[j & 1][m];
+                        const float av = tt == 0 ? av4.x : tt == 1 ? av4.y : av4.z;
+#pragma unroll
+                        for (int q = 0; q < NP; ++q) {
+                            const float4 bv4 = b[j & 1][q];
+                            const float bv = tt == 0 ? bv4.x : tt == 1 ? bv4.y : bv4.z;
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[m][q], 0, 0, 0);   // D^T: rows = channels, cols = pixels
+                        }
                     }
-                    *reinterpret_cast<float4*>(P.ep.out1 + pix * P.ep.ld1 + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    *reinterpret_cast<float4*>(P.ep.out2 + pix * P.ep.ld2 + (n - P.ep.nsplit)) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+
+            // ---- epilogue of the pass: a lane holds channels 16 nb + 4 kg .. + 3 of pixel l15 of each of its two row blocks.
+            // No global load sits between the stores; the bias comes from LDS
+            if (NPASS == 1) fetch_mask();
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int n = 16 * (NP * ps + q) + 4 * kg;
+                    const float4 bb = *reinterpret_cast<const float4*>(&Bs[n]);
+                    float v[4] = {acc[m][q][0] + bb.x, acc[m][q][1] + bb.y, acc[m][q][2] + bb.z, acc[m][q][3] + bb.w};
+                    if (P.ep.lrelu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], leak * v[r]);
+                    }
+                    const bool first = n < P.ep.nsplit;
+                    if (masked && first) {
+                        v[0] *= tm[m][q].x >= 0.f ? 1.f : LEAK; v[1] *= tm[m][q].y >= 0.f ? 1.f : LEAK;
+                        v[2] *= tm[m][q].z >= 0.f ? 1.f : LEAK; v[3] *= tm[m][q].w >= 0.f ? 1.f : LEAK;
+                    }
+                    float* dst = first ? P.ep.out1 + (unsigned)(pix[m] * (int)P.ep.ld1 + n) : P.ep.out2 + (unsigned)(pix[m] * (int)P.ep.ld2 + (n - P.ep.nsplit));
+                    if (okm[m]) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -186,7 +221,7 @@ template <int S, int NB, int TWB>
 void launch_c3(hipStream_t s, C3P P) {
     constexpr int N = 16 * NB, TW = 16 * TWB, TH = 8 / TWB;
     constexpr int IH = S * (TH - 1) + 5, IW = S * (TW - 1) + 5;
-    constexpr size_t lds = (size_t)(((IH * IW * 4 + 3) & ~3) + C3_NCH * 4 * N * 4) * sizeof(float);
+    constexpr size_t lds = (size_t)(((IH * IW * 4 + 3) & ~3) + C3_NCH * 4 * N * 4 + N) * sizeof(float);
     P.tiles_y = (P.hout + TH - 1) / TH;
     P.tiles_x = (P.wout + TW - 1) / TW;
     P.ntiles = P.nimg * P.tiles_y * P.tiles_x;

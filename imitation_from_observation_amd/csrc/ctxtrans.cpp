@@ -124,6 +124,13 @@ struct ctx_handle {
     bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
     int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
     int dp_rc = 0;                // result of the tail bucket's collective (started from inside backward)
+    // Adam beside the backward (fused training steps only: adam_begin / adam_early / adam_end): a slice of the arena is updated on
+    // its own stream as soon as its gradients are final and its parameters have been read for the last time in this step
+    hipStream_t adam_stream = nullptr;
+    hipEvent_t adam_ev[2] = {}, adam_ev_done = nullptr;
+    bool adam_early_on = false;
+    float adam_lr_t = 0.f;
+    std::vector<std::pair<int64_t, int64_t>> adam_done;   // [first, end) slices already enqueued in this step
     // tf.nn.dropout (CTX_VARIANT_REAL with keep_prob < 1): on only while a TRAINING step (forward + backward) is being enqueued
     bool drop_on = false;
     uint64_t drop_seed = 0;
@@ -417,10 +424,61 @@ struct Side {
 };
 constexpr int LANE_CTX = 0, LANE_DW = 1;
 
+// ---- Adam beside the backward ------------------------------------------------------------------------
+// Adam is 7 arena passes of HBM traffic (0.24 ms for ContextSkipNew's 47.6 M parameters) and nothing else in the step is HBM-bound,
+// so the fused training entry points run it in slices on `adam_stream` while the matrix-core kernels of the remaining backward run:
+// a slice may go as soon as (1) its gradients are final and (2) nothing later in this step reads its parameters.  backward() marks
+// those points with adam_early(); adam_end() updates what is left on the compute stream and joins.  The arithmetic per element is
+// that of adam_step (same kernel, same lr_t): results are bit-identical to the unsliced update.  CTX_EARLY_ADAM=0 turns it off.
+void adam_launch(ctx_handle* h, hipStream_t s, int64_t first, int64_t end) {
+    adam(s, h->arena + first, h->arena + h->Ppad + first, h->arena + 2 * h->Ppad + first, h->arena + 3 * h->Ppad + first, end - first,
+         h->adam_lr_t, 0.9f, 0.999f, 1e-8f);
+}
+void adam_begin(ctx_handle* h, float lr) {
+    static const bool env_on = [] { const char* e = getenv("CTX_EARLY_ADAM"); return !(e && e[0] == '0'); }();
+    const double b1 = 0.9, b2 = 0.999;
+    h->adam_t += 1;
+    h->adam_lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t)));
+    h->adam_done.clear();
+    h->adam_early_on = env_on && h->adam_stream && use_lanes(h);
+}
+// [first, end) is final in the order of the CURRENT stream plus (lane >= 0) of that side lane
+void adam_early(ctx_handle* h, int64_t first, int64_t end, int lane) {
+    if (!h->adam_early_on || first < 0 || end <= first || (first & 3) || (end & 3)) return;
+    (void)hipEventRecord(h->adam_ev[0], h->stream);
+    (void)hipStreamWaitEvent(h->adam_stream, h->adam_ev[0], 0);
+    if (lane >= 0) {
+        (void)hipEventRecord(h->adam_ev[1], h->aux[lane]);
+        (void)hipStreamWaitEvent(h->adam_stream, h->adam_ev[1], 0);
+    }
+    adam_launch(h, h->adam_stream, first, end);
+    h->adam_done.emplace_back(first, end);
+}
+void adam_end(ctx_handle* h) {
+    std::sort(h->adam_done.begin(), h->adam_done.end());
+    int64_t at = 0;
+    ProfScope ps(h, "adam", "adam", 0.0);
+    for (size_t i = 0; i <= h->adam_done.size(); ++i) {
+        const int64_t stop = i < h->adam_done.size() ? h->adam_done[i].first : h->Ppad;
+        if (stop > at) adam_launch(h, h->stream, at, stop);
+        if (i < h->adam_done.size()) at = h->adam_done[i].second;
+    }
+    if (!h->adam_done.empty()) {
+        (void)hipEventRecord(h->adam_ev_done, h->adam_stream);
+        (void)hipStreamWaitEvent(h->stream, h->adam_ev_done, 0);
+    }
+    h->adam_early_on = false;
+    h->adam_done.clear();
+}
+
 // the tail of the gradient arena [first, Ppad) (translate/*, deconv/*: arena order is conv_context, conv, translate, deconv) is final
 int dp_reduce_range(ctx_handle* h, int64_t first, int64_t count);
 void fire_bucket(ctx_handle* h, int64_t first) {
-    if (!h->bucket_fn && !h->dp_in_step) return;
+    if (!h->bucket_fn && !h->dp_in_step) {       // plain fused step: nothing after this point reads translate/* or deconv/* parameters
+        { const char* e = getenv("CTX_EARLY_ADAM"); if (e && e[0] == '3') return; }
+        adam_early(h, first, h->Ppad, LANE_DW);
+        return;
+    }
     if (h->dp_in_step) {                         // ctx_dp_train_step: the tail bucket goes out while the encoders' backward is enqueued
         // its filter / bias gradients ran on the side lane: the COLLECTIVE's stream waits for that lane, the compute stream does not
         // (joining the lane into the compute stream here cost 0.3 ms per step: the encoders' backward then queued behind the decoder's
@@ -455,6 +513,8 @@ const char* const K_WCONVT = "wconvt_kernel";       // wide-channel transposed c
 const char* const K_C3CONV = "c3conv_kernel";       // conv from 3 channels, 4-wave blocks (c3conv.hip)
 const char* const K_DCFWD = "dconv_fwd_kernel";
 const char* const K_DCWGRAD = "dconv_wgrad_kernel";
+const char* const K_C3WGRADK = "c3wgrad_kernel";    // filter gradient with a 3-channel big-grid side on whole 128-pixel tiles (c3wgrad.hip)
+const char* dw_label(const DcWgrad& W) { return c3wgrad_ok(W) ? K_C3WGRADK : K_DCWGRAD; }
 const char* const K_COLSUM = "colsum";
 const char* const K_EW = "elementwise";
 
@@ -686,10 +746,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         if (ca == 3 && use_dc3(h)) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
-              ProfScope ps(h, nm_ + " dw", K_DCWGRAD, fl);
               DcWgrad Wg{};
               Wg.big = dy; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dec_in; Wg.ld1 = c1; Wg.c1 = c1; Wg.s2 = h->c[4 - k]; Wg.ld2 = c2; Wg.nmod2 = B; Wg.CB = cb;
               Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = 2 * B; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
+              ProfScope ps(h, nm_ + " dw", dw_label(Wg), fl);
               dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats); }
             if (c3conv_ok(hb, wb, 2, cb, ed)) {
                 ProfScope ps(h, nm_ + " dx", K_C3CONV, fl);
@@ -758,6 +818,11 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         e3.out1 = dA[3]; e3.ld1 = K3; e3.mask = act[3]; e3.ldm = K3;
         if (with_skips) { e3.add1 = h->dSk[3]; e3.lda1 = K3; e3.add2 = h->dSk[3] + (int64_t)B * K3; e3.lda2 = K3; }
         fc_dx(h, scn + "/h4_lin", dA[4], nimg, F, sc.w4, K3, e3);
+        if (!h->bucket_fn && !h->dp_in_step) {   // h4_lin / hz_lin of this encoder (2/3 of its parameters) are done with
+            const int64_t lin0 = h->find((scn + "/h4_lin/Matrix").c_str());
+            const char* e = getenv("CTX_EARLY_ADAM"); if (!(e && e[0] == '2'))
+            adam_early(h, lin0, lin0 + (int64_t)K3 * F + F + (int64_t)F * F + F, dw_lane);
+        }
         for (int k = 3; k >= 0; --k) {
             const int hb = h->hh[k], wb = h->ww[k], hs = hb / 2, wsm = wb / 2;
             const int ca = k ? d << (k - 1) : 3, cb = d << k;
@@ -771,14 +836,17 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             if (k == 0) {
                 Side sd(h, dw_lane);
                 if (!use_dc3(h)) bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);       // (dconv_wgrad returns the column sums of its small operand too)
-                ProfScope ps(h, ln + " dw", use_dc3(h) ? K_DCWGRAD : K_C3WGRAD, fl);
                 if (use_dc3(h)) {
                     DcWgrad Wg{};
                     Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
                     Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = nimg; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
                     Wg.db = sc.gb[k];
+                    ProfScope ps(h, ln + " dw", dw_label(Wg), fl);
                     dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats);
-                } else conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
+                } else {
+                    ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
+                    conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
+                }
                 break;   // no gradient w.r.t. the frame
             }
             { Side sd(h, dw_lane);
@@ -881,12 +949,20 @@ int finish(ctx_handle* h) {
 
 int adam_step(ctx_handle* h, float lr) {
     if (!h->have_grads) return fail(h, CTX_E_STATE, "ctx_dev_adam before any backward");
-    const double b1 = 0.9, b2 = 0.999;
-    h->adam_t += 1;
-    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t));
-    ProfScope ps(h, "adam", "adam", 0.0);
-    adam(h->stream, h->arena, h->arena + h->Ppad, h->arena + 2 * h->Ppad, h->arena + 3 * h->Ppad, h->Ppad, (float)lr_t,
-         (float)b1, (float)b2, 1e-8f);
+    adam_begin(h, lr);
+    h->adam_early_on = false;      // (called after the backward: one launch over the whole arena)
+    adam_end(h);
+    return CTX_OK;
+}
+
+// forward + backward + Adam on the frames in h->img, Adam sliced beside the backward (adam_early)
+int fused_step(ctx_handle* h, int B, float lr) {
+    h->drop_on = true;      // (dropout belongs to the training graph only)
+    forward(h, B, MODE_TRAIN);
+    adam_begin(h, lr);
+    backward(h, B, B);
+    h->drop_on = false;
+    adam_end(h);
     return CTX_OK;
 }
 
@@ -1076,6 +1152,11 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
                 hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
                 rc = fail(h, CTX_E_DEVICE, "side-lane stream/event creation failed");
     }
+    if (rc == CTX_OK && (hipStreamCreateWithFlags(&h->adam_stream, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->adam_ev[0], hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->adam_ev[1], hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->adam_ev_done, hipEventDisableTiming) != hipSuccess))
+        rc = fail(h, CTX_E_DEVICE, "Adam stream/event creation failed");
     if (rc == CTX_OK) {
         e = hipMemsetAsync(h->arena + h->Ppad, 0, 3 * h->Ppad * sizeof(float), h->stream);   // grads, m, v
         if (e == hipSuccess && h->own_arena) e = hipMemsetAsync(h->arena, 0, h->Ppad * sizeof(float), h->stream);
@@ -1109,6 +1190,8 @@ void ctx_destroy(ctx_handle* h) {
         if (h->ev_fork[l]) (void)hipEventDestroy(h->ev_fork[l]);
         if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
     }
+    if (h->adam_stream) { (void)hipStreamSynchronize(h->adam_stream); (void)hipStreamDestroy(h->adam_stream); }
+    for (hipEvent_t e : {h->adam_ev[0], h->adam_ev[1], h->adam_ev_done}) if (e) (void)hipEventDestroy(e);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1379,6 +1462,21 @@ int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_c
     return CTX_OK;
 }
 
+int ctx_dev_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr) {
+    TRY(check_B(h, B));
+    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    TRY(fused_step(h, B, lr));
+    h->last_B = B;
+    { char msg[256]; if (take_launch_error(msg, sizeof msg)) return fail(h, CTX_E_DEVICE, "%s", msg); }
+    HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
 int ctx_set_dropout_seed(ctx_handle* h, uint64_t seed) {
     if (!h) return CTX_E_INVALID;
     h->drop_seed = seed;
@@ -1446,11 +1544,7 @@ int ctx_train_step(ctx_handle* h, const float* src, const float* ctxf, const flo
     if (!src || !ctxf || !tgt) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
     TRY(upload_f32(h, src, ctxf, tgt, B));
-    h->drop_on = true;      // (dropout belongs to the training graph only)
-    forward(h, B, MODE_TRAIN);
-    backward(h, B, B);
-    h->drop_on = false;
-    TRY(adam_step(h, lr));
+    TRY(fused_step(h, B, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return finish(h);
@@ -1465,11 +1559,7 @@ int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx8, co
     HIP_TRY(h, hipMemcpyAsync(h->u8 + nb, src, nb, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->u8 + 2 * nb, ctx8, nb, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, h->u8, h->img, 3 * (int64_t)nb);
-    h->drop_on = true;      // (dropout belongs to the training graph only)
-    forward(h, B, MODE_TRAIN);
-    backward(h, B, B);
-    h->drop_on = false;
-    TRY(adam_step(h, lr));
+    TRY(fused_step(h, B, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return finish(h);
@@ -1668,11 +1758,7 @@ int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_
     HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
-    h->drop_on = true;      // (dropout belongs to the training graph only)
-    forward(h, B, MODE_TRAIN);
-    backward(h, B, B);
-    h->drop_on = false;
-    TRY(adam_step(h, lr));
+    TRY(fused_step(h, B, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     return finish(h);

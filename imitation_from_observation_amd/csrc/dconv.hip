@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256) void dconv_wgrad_reduce_kernel(const float4* _
     }
 }
 
+void dconv_wgrad_reduce(hipStream_t s, const float* slab, int nslab, int M, int NP, int ncols, int n0, int CB, float* out) {
+    const int rb = (M * NP / 4 + 15) / 16;
+    hipLaunchKernelGGL(dconv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, (const float4*)slab, nslab, M, NP, ncols, n0, CB, out);
+}
+
 namespace {
 template <int CAK, int RBW, int WM, int SS>
 void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds) {
@@ -260,6 +265,7 @@ void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds
 
 // dw[tap][a][b] (a: channels of `big`, b: channels of [s1 | s2]); slab: scratch of slab_floats floats
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats) {
+    if (c3wgrad_ok(P)) { c3wgrad(s, P, slab, slab_floats); return; }      // three big-grid channels: the compile-time-geometry kernel (c3wgrad.hip)
     const int CAK = P.CA == 3 ? 4 : P.CA <= 8 ? 8 : P.CA <= 16 ? 16 : 32;
     const int CAP = CAK == 4 ? 4 : CAK + 4;
     // waves: WM groups along M x WK along K (the instantiations below); RBW row blocks of 16 per wave

@@ -57,6 +57,12 @@ void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_t
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   // filter gradient of either, 25 taps in one launch
 
+// the fixed-order sum of nslab partials [M][NP] into out[m][n0 + n] (row stride CB), columns < ncols
+void dconv_wgrad_reduce(hipStream_t s, const float* slab, int nslab, int M, int NP, int ncols, int n0, int CB, float* out);
+// filter gradient with a 3-channel big-grid side on whole 128-pixel tiles (c3wgrad.hip); dconv_wgrad routes to it when c3wgrad_ok
+bool c3wgrad_ok(const DcWgrad& P);
+void c3wgrad(hipStream_t s, const DcWgrad& P, float* slab, int64_t slab_floats);
+
 // conv2d 5x5 (stride 1 | 2, SAME) from a 3-channel tensor to N = 32 | 64 | 128 channels (c3conv.hip): h0_conv forward and the input
 // gradient of d_h4 in both models; epilogue = bias / lrelu / lrelu' mask / column split.  c3conv_ok: the shapes it is built for.
 bool c3conv_ok(int hin, int win, int stride, int N, const Epi& ep);

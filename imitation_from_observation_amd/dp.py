@@ -70,6 +70,11 @@ class HipEngine:
     def adam(self, lr):
         self.translator.dev_adam(lr)
 
+    def train_step(self, src, ctx, tgt, lr):
+        """The whole single-replica step in one ABI call (ctx_dev_train_step): same result as forward_backward + adam, with
+        Adam's slices enqueued beside the remaining backward."""
+        self.translator.dev_train_step(self._ptr(src), self._ptr(ctx), self._ptr(tgt), src.shape[0], lr)
+
     def scalars_tensor(self):
         """{loss, simloss, recon1, recon2} of the last forward as a device tensor: a view of the f32[4] the loss kernel wrote
         (ctx_dev_scalar_buf) -- stream-ordered with the step, no host round trip."""
@@ -119,6 +124,9 @@ class DataParallelTrainer:
                 works.append(dist.all_reduce(self.engine.grads[:split[0]], op=dist.ReduceOp.SUM, async_op=True))
                 for w in works:
                     w.wait()
+            elif self.world == 1 and not self.force_collectives and hasattr(self.engine, "train_step"):
+                self.engine.train_step(src, ctx, tgt, lr)      # nothing to reduce: the fused step
+                return
             else:
                 self.engine.forward_backward(src, ctx, tgt, sim_batch=B * self.world)
                 if self.world > 1 or self.force_collectives:

@@ -410,6 +410,11 @@ class Translator:
         self._ck(self._lib.ctx_dev_forward_backward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx),
                                                      ctypes.c_void_p(d_tgt), B, sim_batch))
 
+    def dev_train_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4):
+        """One whole training step (forward + backward + Adam) on device-resident frames, asynchronous on the handle's stream:
+        bit-identical to dev_forward_backward + dev_adam, with Adam's slices enqueued beside the remaining backward."""
+        self._ck(self._lib.ctx_dev_train_step(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt), B, float(lr)))
+
     def set_grad_bucket_callback(self, fn):
         """fn(first, count) is called from inside dev_forward_backward when gradients [first, first+count) of the gradient
         arena (translate/*, deconv/*) are final in stream order; None clears it (data-parallel overlap, dp.py)."""

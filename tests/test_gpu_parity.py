@@ -396,6 +396,34 @@ def test_device_phase_api_equals_host_api(T):
     dp.translator.close()
 
 
+@pytest.mark.parametrize("variant,H,W,d,F,B", [("skipnew", 64, 64, 64, 1024, 64), ("skipnew", 32, 32, 32, 128, 4), ("real", 36, 64, 32, 100, 16)])
+def test_fused_step_with_adam_beside_the_backward_is_bit_identical(T, variant, H, W, d, F, B):
+    """ctx_dev_train_step (Adam's slices enqueued on their own stream beside the remaining backward) == ctx_dev_forward_backward
+    followed by ctx_dev_adam, bit for bit: parameters, both Adam moments and the step count after three steps, at a size where
+    the side lanes and the position-major launches are in play."""
+    import torch
+    rng = np.random.default_rng(17)
+    fr = [torch.from_numpy(o.preprocess_u8(rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8))).cuda() for _ in range(3)]
+    kw = dict(df_dim=d, featsize=F, max_batch=B) if variant == "skipnew" else dict(featsize=F, max_batch=B, variant="real")
+    res = []
+    for fused in (True, False):
+        with T(H, W, **kw) as tr:
+            tr.init_params(5)
+            for _ in range(3):
+                if fused:
+                    tr.dev_train_step(*(t.data_ptr() for t in fr), B, 1e-3)
+                else:
+                    tr.dev_forward_backward(*(t.data_ptr() for t in fr), B)
+                    tr.dev_adam(1e-3)
+            sc = tr.dev_scalars()
+            m, v, t = tr.get_adam_state()
+            res.append((tr.get_params_flat(), m, v, t, sc))
+    assert res[0][3] == res[1][3] == 3 and res[0][4] == res[1][4]
+    for a, b in zip(res[0][:3], res[1][:3]):
+        np.testing.assert_array_equal(a, b)
+    assert np.abs(res[0][1]).max() > 0
+
+
 def test_max_batch_beyond_32bit_offsets_is_refused(T):
     """Loaders use 32-bit byte offsets per tensor: a max_batch whose activations would pass 2 GiB fails at create, with a message."""
     from imitation_from_observation_amd import CtxError
