@@ -13,7 +13,7 @@ def group(k):
     if not m:
         if "adam_kernel" in k:
             return "adam"
-        d = re.match(r"void ctx::(?:\(anonymous namespace\)::)?(dconv_fwd_kernel|dconv_wgrad_kernel|convt3_kernel|wconvt_kernel|c3conv_kernel)<", k)     # the labels ctx_profile_step uses for the direct kernels
+        d = re.match(r"void ctx::(?:\(anonymous namespace\)::)?(dconv_fwd_kernel|dconv_wgrad_kernel|convt3_kernel|wconvt_kernel|c3conv_kernel|c3wgrad_kernel)<", k)     # the labels ctx_profile_step uses for the direct kernels
         return d.group(1) if d else k
     a, b = m.group(2), m.group(3)
     if a.startswith("KmConvTGather"):
