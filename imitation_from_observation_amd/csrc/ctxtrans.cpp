@@ -429,13 +429,18 @@ constexpr int LANE_CTX = 0, LANE_DW = 1;
 // so the fused training entry points run it in slices on `adam_stream` while the matrix-core kernels of the remaining backward run:
 // a slice may go as soon as (1) its gradients are final and (2) nothing later in this step reads its parameters.  backward() marks
 // those points with adam_early(); adam_end() updates what is left on the compute stream and joins.  The arithmetic per element is
-// that of adam_step (same kernel, same lr_t): results are bit-identical to the unsliced update.  CTX_EARLY_ADAM=0 turns it off.
+// that of adam_step (same kernel, same lr_t): results are bit-identical to the unsliced update (tests/test_gpu_parity.py).
+// MEASURED (round 3, six back-to-back bench runs): no gain -- 13.79 / 13.81 ms with the slices against 13.79 / 13.79 without, tail
+// slice only 13.76, encoder slices only 13.83.  The matrix-core kernels it would hide under own the CUs' registers and LDS, so the
+// Adam blocks displace their blocks instead of running beside them: the step costs the sum of the work either way.  OFF unless
+// CTX_EARLY_ADAM=1 (read at every step, so a test can switch it).
 void adam_launch(ctx_handle* h, hipStream_t s, int64_t first, int64_t end) {
     adam(s, h->arena + first, h->arena + h->Ppad + first, h->arena + 2 * h->Ppad + first, h->arena + 3 * h->Ppad + first, end - first,
          h->adam_lr_t, 0.9f, 0.999f, 1e-8f);
 }
 void adam_begin(ctx_handle* h, float lr) {
-    static const bool env_on = [] { const char* e = getenv("CTX_EARLY_ADAM"); return !(e && e[0] == '0'); }();
+    const char* ev = getenv("CTX_EARLY_ADAM");
+    const bool env_on = ev && ev[0] == '1';
     const double b1 = 0.9, b2 = 0.999;
     h->adam_t += 1;
     h->adam_lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t)));
@@ -475,7 +480,6 @@ void adam_end(ctx_handle* h) {
 int dp_reduce_range(ctx_handle* h, int64_t first, int64_t count);
 void fire_bucket(ctx_handle* h, int64_t first) {
     if (!h->bucket_fn && !h->dp_in_step) {       // plain fused step: nothing after this point reads translate/* or deconv/* parameters
-        { const char* e = getenv("CTX_EARLY_ADAM"); if (e && e[0] == '3') return; }
         adam_early(h, first, h->Ppad, LANE_DW);
         return;
     }
@@ -820,7 +824,6 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         fc_dx(h, scn + "/h4_lin", dA[4], nimg, F, sc.w4, K3, e3);
         if (!h->bucket_fn && !h->dp_in_step) {   // h4_lin / hz_lin of this encoder (2/3 of its parameters) are done with
             const int64_t lin0 = h->find((scn + "/h4_lin/Matrix").c_str());
-            const char* e = getenv("CTX_EARLY_ADAM"); if (!(e && e[0] == '2'))
             adam_early(h, lin0, lin0 + (int64_t)K3 * F + F + (int64_t)F * F + F, dw_lane);
         }
         for (int k = 3; k >= 0; --k) {

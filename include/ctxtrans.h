@@ -204,10 +204,11 @@ int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const
                     int B);
 /* One whole training step on device-resident frames: forward + backward + Adam (train_script.py:163's
  * sess.run([..., optim]) without the host copies), enqueued on the handle's stream, no synchronisation.
- * Same result, bit for bit, as ctx_dev_forward_backward(sim_batch = 0) followed by ctx_dev_adam(lr); because
- * the learning rate is known up front, Adam's update of a parameter slice is enqueued beside the remaining
- * backward as soon as that slice's gradients are final and its parameters are no longer read (Adam is the one
- * HBM-bound part of the step).  The host-fed steps (ctx_train_step, _u8, _sampled) do the same. */
+ * Same result, bit for bit, as ctx_dev_forward_backward(sim_batch = 0) followed by ctx_dev_adam(lr).  With
+ * CTX_EARLY_ADAM=1 in the environment, Adam's update of a parameter slice is enqueued beside the remaining
+ * backward as soon as that slice's gradients are final and its parameters are no longer read (measured: no
+ * gain on MI355X, so off by default; still bit-identical).  The host-fed steps (ctx_train_step, _u8, _sampled)
+ * go through the same code. */
 int ctx_dev_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B,
                        float lr);
 /* Fused multi-tensor Adam over the whole arena with the gradients currently in the grad arena. */
