@@ -46,9 +46,14 @@ for H, W in ((36, 64), (64, 64)):
             for _ in range(3):
                 fn(x)
             n = 20
-            t0 = time.perf_counter()
+            ts = []
             for _ in range(n):
+                t0 = time.perf_counter()
                 fn(x)
-            dt = (time.perf_counter() - t0) / n
-            print(f"{name:34s} {H:3d}x{W:<3d} {B:5d} {dt * 1e3:9.3f} {B / dt:10.0f}")
+                ts.append(time.perf_counter() - t0)
+            dt = sum(ts) / n
+            note = ""
+            if max(ts) > 3 * sorted(ts)[n // 2]:          # a few slow calls inside the mean: say so
+                note = "   (median %.3f ms, max %.3f ms)" % (1e3 * sorted(ts)[n // 2], 1e3 * max(ts))
+            print(f"{name:34s} {H:3d}x{W:<3d} {B:5d} {dt * 1e3:9.3f} {B / dt:10.0f}{note}")
     tr.close()
