@@ -111,6 +111,7 @@ SIGNATURES = {
     "ctx_dp_allreduce_grads": (_c.c_int, [_P]),
     "ctx_dp_train_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _F]),
     "ctx_dp_scalars": (_c.c_int, [_P, _F]),
+    "ctx_dp_allreduce_host_f64": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.c_size_t]),
     "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
                                     _c.POINTER(_c.c_int)]),
     "ctx_debug_read": (_c.c_int, [_P, _c.c_char_p, _F, _c.c_size_t]),

@@ -1712,6 +1712,26 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     return CTX_OK;
 }
 
+int ctx_dp_allreduce_host_f64(ctx_handle* h, double* buf, size_t n) {
+    if (!h || (!buf && n)) return CTX_E_INVALID;
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    if (n == 0) return CTX_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    double* d = nullptr;                                   // (a cache-build call, a few MB once per rollout batch: allocated per call)
+    if (hipMalloc((void**)&d, n * sizeof(double)) != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%zu bytes) for the host all-reduce", n * sizeof(double));
+    int rc = CTX_OK;
+    do {
+        if (hipMemcpyAsync(d, buf, n * sizeof(double), hipMemcpyHostToDevice, h->dp_stream) != hipSuccess) { rc = fail(h, CTX_E_DEVICE, "host all-reduce: upload failed"); break; }
+        const ncclResult_t r = rccl().AllReduce(d, d, n, ncclDouble, ncclSum, h->dp_comm, h->dp_stream);
+        if (r != ncclSuccess) { rc = fail(h, CTX_E_DEVICE, "ncclAllReduce(f64): %s", rccl().GetErrorString ? rccl().GetErrorString(r) : "error"); break; }
+        if (hipMemcpyAsync(buf, d, n * sizeof(double), hipMemcpyDeviceToHost, h->dp_stream) != hipSuccess) { rc = fail(h, CTX_E_DEVICE, "host all-reduce: download failed"); break; }
+    } while (0);
+    const hipError_t es = hipStreamSynchronize(h->dp_stream);
+    (void)hipFree(d);
+    if (rc == CTX_OK && es != hipSuccess) rc = fail(h, CTX_E_DEVICE, "host all-reduce: %s", hipGetErrorString(es));
+    return rc;
+}
+
 int ctx_dp_scalars(ctx_handle* h, float scalars[4]) {
     if (!h || !scalars) return CTX_E_INVALID;
     if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");

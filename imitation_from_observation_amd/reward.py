@@ -69,9 +69,10 @@ class TranslatorReward:
         In mode 'oursinception' only the first 50 videos are used (`nvideos = 50`, base.py:203-204) and the reference feeds
         `validdata[::skip, i]` to its uint8 placeholder WITHOUT the (x+1)*127.5 conversion (:212-213) -- so a uint8 demo
         tensor is taken as it is there; a float one is converted like in the other modes (deviations).
-        distributed=True (inside an initialised torch.distributed group, one rank per GPU): the demo videos
-        are sharded rank::world, every rank translates its shard and the partial feature / frame sums are
-        combined with ONE all-reduce per viewpoint -- the demo means are a plain sum over videos."""
+        distributed=True (one rank per GPU): the demo videos are sharded rank::world, every rank translates its shard and
+        the partial feature / frame sums are combined with ONE all-reduce per viewpoint -- the demo means are a plain sum
+        over videos.  The group is the translator's own RCCL group when it has one (Translator.dp_init:
+        ctx_dp_allreduce_host_f64, no torch in the sampler process), else an initialised torch.distributed group."""
         validdata = np.asarray(validdata)
         nvid = validdata.shape[1]
         if self.nvideos_cap is not None:
@@ -81,10 +82,16 @@ class TranslatorReward:
         self.means, self.imgs = [], []
         per_call = max(1, self.tr.max_batch // bs)
         rank, world = 0, 1
+        cabi = False
         if distributed:
-            import torch
-            import torch.distributed as dist
-            rank, world = dist.get_rank(), dist.get_world_size()
+            own = getattr(self.tr, "dp_world", None)
+            if callable(own) and own()[1] > 1:
+                rank, world = own()
+                cabi = True
+            else:
+                import torch
+                import torch.distributed as dist
+                rank, world = dist.get_rank(), dist.get_world_size()
         mine = list(range(rank, nvid, world))
         for vp in range(self.nvp):
             ctx = np.ascontiguousarray(first_frames[vp], dtype=np.uint8)
@@ -99,7 +106,10 @@ class TranslatorReward:
                 timg, tfeat = self.tr.translate(u8, ctx)                   # [translated_z, out], base.py:216-218
                 fsum += tfeat.reshape(len(vids), bs, -1).sum(0)
                 isum += timg.reshape((len(vids), bs) + pshape).sum(0)
-            if distributed and world > 1:
+            if cabi:
+                flat = self.tr.dp_allreduce_host(np.concatenate([fsum.ravel(), isum.ravel()]))
+                fsum, isum = flat[:fsum.size].reshape(fsum.shape), flat[fsum.size:].reshape(isum.shape)
+            elif distributed and world > 1:
                 flat = torch.from_numpy(np.concatenate([fsum.ravel(), isum.ravel()]))
                 if dist.get_backend() == "nccl":
                     flat = flat.cuda()

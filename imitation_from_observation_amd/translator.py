@@ -472,6 +472,19 @@ class Translator:
         if scalars:
             return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
+    def dp_world(self):
+        """(rank, world) of this handle's RCCL group; (0, 1) before dp_init."""
+        r, w = ctypes.c_int(0), ctypes.c_int(1)
+        self._ck(self._lib.ctx_dp_world(self._h, ctypes.byref(r), ctypes.byref(w)))
+        return int(r.value), int(w.value)
+
+    def dp_allreduce_host(self, arr):
+        """In-place SUM over the ranks of a contiguous float64 numpy array (synchronous): the reward hook's sharded demo cache."""
+        if not (isinstance(arr, np.ndarray) and arr.dtype == np.float64 and arr.flags.c_contiguous):
+            raise ValueError("dp_allreduce_host wants a C-contiguous float64 array")
+        self._ck(self._lib.ctx_dp_allreduce_host_f64(self._h, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), arr.size))
+        return arr
+
     def dp_scalars(self):
         sc = np.empty(4, np.float32)
         self._ck(self._lib.ctx_dp_scalars(self._h, _fp(sc)))

@@ -260,6 +260,11 @@ int ctx_dp_allreduce_grads(ctx_handle* h);
 int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr,
                       float scalars[4]);
 int ctx_dp_scalars(ctx_handle* h, float scalars[4]);
+/* In-place SUM over the ranks of a HOST buffer of doubles (synchronous; through a device staging buffer and ncclAllReduce
+ * on the handle's collective stream).  For the sharded demo cache of the reward hook (sampler/base.py:195-223 builds it on
+ * one device; reward.py shards the demo videos rank::world and adds the partial feature / frame sums): the group that
+ * ctx_dp_init made serves it, no second communication library in the sampler process. */
+int ctx_dp_allreduce_host_f64(ctx_handle* h, double* buf, size_t n);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* One entry per launch group of a train step (a layer's forward, input gradient, filter gradient,

@@ -67,6 +67,38 @@ def main():
     tr.sync()
     out["params3"] = tr.get_params_flat()
     out["adam_step3"] = np.int64(tr.get_adam_state()[2])
+    # (c) the reward hook's demo cache, sharded over the SAME group (ctx_dp_allreduce_host_f64): 5 demo videos of 25 frames, 2 viewpoints
+    from imitation_from_observation_amd.reward import TranslatorReward
+    drng = np.random.default_rng(23)
+    validdata = drng.integers(0, 256, (25, 5, H, W, 3), dtype=np.uint8).astype(np.float32) / 127.5 - 1.0
+    first = [drng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(2)]
+    trw = Translator(H, W, D, F, max_batch=50)          # the sampler-side translator (its own handle), same group
+    trw.set_params_flat(out["params3"])
+    idfile2 = os.path.join(work, "uid2.bin")
+    if rank == 0:
+        uid2 = Translator.dp_unique_id()
+        with open(idfile2 + ".tmp", "wb") as f:
+            f.write(uid2)
+        os.rename(idfile2 + ".tmp", idfile2)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile2):
+            if time.time() - t0 > 60:
+                raise SystemExit("rank 0 never published the second unique id")
+            time.sleep(0.01)
+        uid2 = open(idfile2, "rb").read()
+    trw.dp_init(uid2, rank, world)
+    hook = TranslatorReward(trw, nvp=2, scale=0.01).build_demo_cache(validdata, first, distributed=True)
+    out["cache_means"] = np.stack(hook.means)
+    out["cache_imgs"] = np.stack(hook.imgs)
+    if rank == 0:                                       # the same cache built by one rank alone
+        solo = Translator(H, W, D, F, max_batch=50)
+        solo.set_params_flat(out["params3"])
+        h1 = TranslatorReward(solo, nvp=2, scale=0.01).build_demo_cache(validdata, first)
+        out["solo_means"] = np.stack(h1.means)
+        out["solo_imgs"] = np.stack(h1.imgs)
+        solo.close()
+    trw.close()
     np.savez(os.path.join(work, f"rank{rank}.npz"), **out)
     tr.close()
     print(f"rank {rank} ok", flush=True)

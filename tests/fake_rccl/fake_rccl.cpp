@@ -51,7 +51,7 @@ struct Comm {
 struct Op {                                // one piece of one collective, handed to the stream's host function
     Comm* c;
     size_t bytes;
-    int kind;                              // 0 = sum all-reduce of floats, 1 = broadcast
+    int kind;                              // 0 = sum all-reduce of floats, 1 = broadcast, 2 = sum all-reduce of doubles
     int root;
 };
 
@@ -81,9 +81,17 @@ void host_step(void* user) {               // runs on the stream (hipLaunchHostF
     Op* op = (Op*)user;
     Comm* c = op->c;
     char* mine = c->payload + (size_t)c->rank * CAP;
-    if (op->kind == 0 || c->rank == op->root) memcpy(mine, c->pinned, op->bytes);
+    if (op->kind != 1 || c->rank == op->root) memcpy(mine, c->pinned, op->bytes);
     if (barrier(c)) {
-        if (op->kind == 0) {
+        if (op->kind == 2) {
+            double* out = (double*)c->pinned;
+            const size_t n = op->bytes / sizeof(double);
+            memcpy(out, c->payload, op->bytes);
+            for (int r = 1; r < c->world; ++r) {
+                const double* s = (const double*)(c->payload + (size_t)r * CAP);
+                for (size_t i = 0; i < n; ++i) out[i] += s[i];
+            }
+        } else if (op->kind == 0) {
             float* out = (float*)c->pinned;
             const size_t n = op->bytes / sizeof(float);
             memcpy(out, c->payload, op->bytes);                                  // rank 0's shard first, then 1, 2, ... : same order everywhere
@@ -164,7 +172,8 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm) {
 }
 
 ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataType_t dt, ncclRedOp_t op, ncclComm_t comm, hipStream_t s) {
-    if (dt != ncclFloat || op != ncclSum) return ncclInvalidArgument;
+    if (op != ncclSum || (dt != ncclFloat && dt != ncclDouble)) return ncclInvalidArgument;
+    if (dt == ncclDouble) return run((Comm*)comm, send, recv, count * sizeof(double), 2, 0, s);
     return run((Comm*)comm, send, recv, count * sizeof(float), 0, 0, s);
 }
 
@@ -181,7 +190,7 @@ const char* ncclGetErrorString(ncclResult_t r) {
         case ncclSuccess: return "no error";
         case ncclUnhandledCudaError: return "fake_rccl: HIP call failed";
         case ncclSystemError: return "fake_rccl: shared-memory rendezvous failed or a rank timed out";
-        case ncclInvalidArgument: return "fake_rccl: unsupported argument (f32 sum / broadcast only)";
+        case ncclInvalidArgument: return "fake_rccl: unsupported argument (f32 / f64 sum, f32 broadcast only)";
         default: return "fake_rccl: error";
     }
 }

@@ -21,13 +21,16 @@ FAKE = os.path.join(HERE, "fake_rccl", "libfakerccl.so")
 
 def test_fake_rccl_exports_what_libctxtrans_binds():
     """CPU: the stand-in is built (by __graft_entry__.build()) and exports the eight symbols rccl_load() looks up."""
-    import ctypes
     if not os.path.exists(FAKE):
         subprocess.run(["make", "-C", os.path.dirname(FAKE)], check=True)
-    lib = ctypes.CDLL(FAKE)
-    for s in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclBroadcast", "ncclGroupStart",
-              "ncclGroupEnd", "ncclGetErrorString"):
-        assert hasattr(lib, s), s
+    # looked up in a CHILD process: the stand-in links the system HIP runtime, and loading that into the pytest process ahead of
+    # torch's bundled one leaves a later GPU test of the same process without a device
+    code = ("import ctypes, sys; lib = ctypes.CDLL(sys.argv[1]); "
+            "missing = [s for s in sys.argv[2:] if not hasattr(lib, s)]; print(missing); sys.exit(1 if missing else 0)")
+    syms = ["ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclBroadcast", "ncclGroupStart",
+            "ncclGroupEnd", "ncclGetErrorString"]
+    r = subprocess.run([sys.executable, "-c", code, FAKE] + syms, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
@@ -100,3 +103,10 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
     # way, so the update is judged as a whole (direction and size), not entry by entry
     assert np.corrcoef(delta, want_delta)[0, 1] > 0.999
     assert abs(np.linalg.norm(delta) / np.linalg.norm(want_delta) - 1.0) < 1e-2
+    # ---- the reward hook's demo cache sharded over the handle's own group (ctx_dp_allreduce_host_f64, no torch.distributed):
+    # both ranks hold the same cache, and it is the one a single rank builds from all videos (f64 sums in another order)
+    np.testing.assert_array_equal(z[0]["cache_means"], z[1]["cache_means"])
+    np.testing.assert_array_equal(z[0]["cache_imgs"], z[1]["cache_imgs"])
+    np.testing.assert_allclose(z[0]["cache_means"], z[0]["solo_means"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(z[0]["cache_imgs"], z[0]["solo_imgs"], rtol=1e-6, atol=1e-7)
+    assert np.abs(z[0]["cache_means"]).max() > 0
