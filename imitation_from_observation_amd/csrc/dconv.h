@@ -325,13 +325,72 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
                 if (g + 1 < g1) { tnext = tab[(g + 1) * 4 + kg]; fetch(1); mma(0); mma(1); }
                 else mma(0);
             };
+            // The terms an element's epilogue needs from memory (skip-gradient adds, the saved activation behind lrelu') are requested
+            // HERE, in front of the class's MFMA loop, for all of the wave's row blocks: their latency runs under the MFMAs, and no
+            // load sits between the stores below (a load's wait also waits for the stores issued before it: the per-row-block
+            // load -> wait -> store chain costs one store round trip per row block and class).  MI * NB > 4 -- 64-column tiles with
+            // two or three row blocks per wave -- has no registers for that and keeps the per-row-block batches.
+            constexpr bool PRE = MI * NB <= 4;
+            constexpr int PM = PRE ? MI : 1, PN = PRE ? NB : 1;
+            int64_t ppix[PM];
+            bool pok[PM];
+            float4 p1[PM][PN], p2[PM][PN], pm[PM][PN];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int rb = wv + DC_NW * mi, ty = rb / rbw, x = tx0 + (rb - ty * rbw) * 16 + l15, y = ty0 + ty;
+                    pok[mi] = rb < nrb && y < P.hlog && x < P.wlog;
+                    ppix[mi] = pok[mi] ? ((int64_t)img * P.hout + (P.osc * y + cl.oy)) * P.wout + (P.osc * x + cl.ox) : 0;   // (a pixel that exists)
+                    if (P.ep.add1) {
+                        const int64_t pa = (P.ep.add1_mod && ppix[mi] >= P.ep.add1_mod) ? ppix[mi] - P.ep.add1_mod : ppix[mi];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) p1[mi][nb] = ldg4(P.ep.add1 + pa * P.ep.lda1 + (ncol[nb] < P.N ? ncol[nb] : 0));
+                    }
+                    if (P.ep.add2) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) p2[mi][nb] = ldg4(P.ep.add2 + ppix[mi] * P.ep.lda2 + (ncol[nb] < P.N ? ncol[nb] : 0));
+                    }
+                    if (P.ep.mask) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            pm[mi][nb] = ldg4(P.ep.mask + ppix[mi] * P.ep.ldm + (ncol[nb] < P.N && ncol[nb] < P.ep.nsplit ? ncol[nb] : 0));
+                    }
+                }
+            }
             if (wv + DC_NW * (MI - 1) < nrb) run(std::integral_constant<int, MI>{});
             else if constexpr (MI > 1) { if (active) run(std::integral_constant<int, MI - 1>{}); }
             // ---- epilogue of this class.  D^T: a lane has channels ncol[nb] .. + 3 of pixel x = l15 of each of its row blocks.  The
             // terms an element needs from memory (skip-gradient adds, the saved activation behind lrelu') are loaded for a whole row
             // block first, branch-free, and only then applied (epi_store's load -> wait -> store chain per element took
             // longer than the MFMA loop).
-            {
+            if constexpr (PRE) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (!pok[mi]) continue;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int n = ncol[nb];
+                        if (n >= P.N) continue;
+                        float v[4] = {acc[mi][nb][0] + bias_v[nb].x, acc[mi][nb][1] + bias_v[nb].y, acc[mi][nb][2] + bias_v[nb].z, acc[mi][nb][3] + bias_v[nb].w};
+                        if (P.ep.add1) { v[0] += p1[mi][nb].x; v[1] += p1[mi][nb].y; v[2] += p1[mi][nb].z; v[3] += p1[mi][nb].w; }
+                        if (P.ep.add2) { v[0] += p2[mi][nb].x; v[1] += p2[mi][nb].y; v[2] += p2[mi][nb].z; v[3] += p2[mi][nb].w; }
+                        if (P.ep.lrelu) {
+                            const float lk = P.ep.lrelu == 2 ? 0.f : LEAK;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lk * v[r]);
+                        }
+                        if (n < P.ep.nsplit) {
+                            if (P.ep.mask) {
+                                v[0] *= pm[mi][nb].x >= 0.f ? 1.f : LEAK; v[1] *= pm[mi][nb].y >= 0.f ? 1.f : LEAK;
+                                v[2] *= pm[mi][nb].z >= 0.f ? 1.f : LEAK; v[3] *= pm[mi][nb].w >= 0.f ? 1.f : LEAK;
+                            }
+                            *reinterpret_cast<float4*>(P.ep.out1 + ppix[mi] * P.ep.ld1 + n) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+                            *reinterpret_cast<float4*>(P.ep.out2 + ppix[mi] * P.ep.ld2 + (n - P.ep.nsplit)) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+                }
+            } else {
                 int64_t pix[MI];
                 bool okp[MI];
 #pragma unroll
