@@ -1206,26 +1206,93 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     // position-major launches (rowmode 4 / 5): the destination pixel is LINEAR in the row (= image) index; the
     // block-uniform part is resolved once here, outside the unrolled loops
     const RowMap rmap = epi_rowmap(ep, prob);
+    if (ep.slab) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m >= M) continue;
-            if (ep.slab) {
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= M) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int n = n0 + (wn * NI + ni) * 32 + l31;
                     if (n < N) ep.slab[(((int64_t)split * nprob + prob) * M + m) * N + n] = acc[mi][ni][r];
                 }
-            } else {
-                int64_t pix;
-                if (rmap.linear) pix = rmap.base + (int64_t)m * rmap.stride;
-                else if (!epi_row(ep, prob, m, pix)) continue;
+            }
+        }
+        return;
+    }
+    // Everything an element needs from memory (bias, skip-gradient adds, the saved activation behind lrelu') is requested for GR = 4 / NI
+    // rows at a time (four loads per term in flight: a larger batch raises the kernel's register count above what its main loop needs, and the small kernels of the side lanes then no longer fit beside it on a SIMD -- measured: conv family -1 % serialised, step +0.03 ms) and only then applied and stored.  epi_store per element -- load, wait, store -- made every one of the 16 MI
+    // row steps a store round trip: the s_waitcnt vmcnt(0) in front of a loaded value also waits for the stores issued before it
+    // (the ISA of the conv forward kernel had 128 loads, each behind its own vmcnt(0), between its 96 stores -- the bias was re-read
+    // per element because the stores in between might alias it).
+    constexpr int GR = 4 / NI > 0 ? 4 / NI : 1;
+    int nn[NI];
+    bool nok[NI];
+    float bv[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        nn[ni] = n0 + (wn * NI + ni) * 32 + l31;
+        nok[ni] = nn[ni] < N;
+        bv[ni] = (ep.bias && nok[ni]) ? ep.bias[nn[ni]] : 0.f;
+    }
+    const float lk = ep.lrelu == 2 ? 0.f : LEAK;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int g = 0; g < 16 / GR; ++g) {
+            int64_t pix[GR];
+            bool ok[GR];
+            float a1[GR][NI], a2[GR][NI], mk[GR][NI];
+#pragma unroll
+            for (int j = 0; j < GR; ++j) {
+                const int r = GR * g + j;
+                const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                ok[j] = m < M;
+                pix[j] = 0;
+                if (ok[j]) {
+                    if (rmap.linear) pix[j] = rmap.base + (int64_t)m * rmap.stride;
+                    else ok[j] = epi_row(ep, prob, m, pix[j]);
+                }
+                if (!ok[j]) pix[j] = 0;                               // (loads below stay inside the tensors)
+            }
+            if (ep.add1) {
+#pragma unroll
+                for (int j = 0; j < GR; ++j) {
+                    const int64_t pa = (ep.add1_mod && pix[j] >= ep.add1_mod) ? pix[j] - ep.add1_mod : pix[j];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) a1[j][ni] = ep.add1[pa * ep.lda1 + (nok[ni] ? nn[ni] : 0)];
+                }
+            }
+            if (ep.add2) {
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) a2[j][ni] = ep.add2[pix[j] * ep.lda2 + (nok[ni] ? nn[ni] : 0)];
+            }
+            if (ep.mask) {
+#pragma unroll
+                for (int j = 0; j < GR; ++j)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) mk[j][ni] = ep.mask[pix[j] * ep.ldm + ((nok[ni] && nn[ni] < ep.nsplit) ? nn[ni] : 0)];
+            }
+#pragma unroll
+            for (int j = 0; j < GR; ++j) {
+                if (!ok[j]) continue;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int n = n0 + (wn * NI + ni) * 32 + l31;
-                    if (n < N) epi_store(ep, prob, pix, n, acc[mi][ni][r]);
+                    if (!nok[ni]) continue;
+                    float v = acc[mi][ni][GR * g + j] + bv[ni];
+                    if (ep.add1) v += a1[j][ni];
+                    if (ep.add2) v += a2[j][ni];
+                    if (ep.lrelu) v = fmaxf(v, lk * v);
+                    if (nn[ni] < ep.nsplit) {
+                        if (ep.mask) v *= (mk[j][ni] >= 0.f) ? 1.f : LEAK;
+                        ep.out1[(int64_t)prob * ep.prob_stride + pix[j] * ep.ld1 + nn[ni]] = v;
+                    } else {
+                        ep.out2[pix[j] * ep.ld2 + (nn[ni] - ep.nsplit)] = v;
+                    }
                 }
             }
         }
