@@ -519,6 +519,7 @@ const char* const K_DCFWD = "dconv_fwd_kernel";
 const char* const K_DCWGRAD = "dconv_wgrad_kernel";
 const char* const K_C3WGRADK = "c3wgrad_kernel";    // filter gradient with a 3-channel big-grid side on whole 128-pixel tiles (c3wgrad.hip)
 const char* dw_label(const DcWgrad& W) { return c3wgrad_ok(W) ? K_C3WGRADK : K_DCWGRAD; }
+const char* const K_RCHAIN = "rchain";               // ContextAEReal's FC middle in three launches (rchain.hip)
 const char* const K_COLSUM = "colsum";
 const char* const K_EW = "elementwise";
 

@@ -63,6 +63,15 @@ void dconv_wgrad_reduce(hipStream_t s, const float* slab, int nslab, int M, int 
 bool c3wgrad_ok(const DcWgrad& P);
 void c3wgrad(hipStream_t s, const DcWgrad& P, float* slab, int64_t slab_floats);
 
+// ContextAEReal's fully connected middle (h4_lin, hz_lin, trans_h0, trans_z, d_h0_lin) in three launches (rchain.hip): rows of one
+// triple stay in one block.  W[10] = {W4, b4, Wz, bz, Wt0, bt0, Wtz, btz, Wd0, bd0} (padded layouts of the arena); G likewise.
+bool rchain_ok(int Fp, int64_t D0p, int nset, bool drop, int prec);
+void rchain_fwd(hipStream_t s, int B, int D0p, const float* a3, float* a4, float* Z, float* th0, float* dz, const float* const W[10]);
+void rchain_bwd(hipStream_t s, int B, int D0p, const float* dDz, const float* dsim2, float* dZ, float* dth0, float* dA4, float* dA3, const float* Z,
+                const float* th0, const float* a4, const float* a3, const float* dSk3, const float* const W[10]);
+void rchain_dw(hipStream_t s, int B, int D0p, const float* a3, const float* a4, const float* Z, const float* th0, const float* dA4, const float* dZ,
+               const float* dth0, const float* dDz, float* const G[10]);
+
 // conv2d 5x5 (stride 1 | 2, SAME) from a 3-channel tensor to N = 32 | 64 | 128 channels (c3conv.hip): h0_conv forward and the input
 // gradient of d_h4 in both models; epilogue = bias / lrelu / lrelu' mask / column split.  c3conv_ok: the shapes it is built for.
 bool c3conv_ok(int hin, int win, int stride, int N, const Epi& ep);
