@@ -225,12 +225,11 @@ void launch_c3(hipStream_t s, C3P P) {
     P.tiles_y = (P.hout + TH - 1) / TH;
     P.tiles_x = (P.wout + TW - 1) / TW;
     P.ntiles = P.nimg * P.tiles_y * P.tiles_x;
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)c3conv_kernel<S, NB, TWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
-    int per_cu = (int)((160 * 1024) / (lds + 512));
+    ensure_dyn_lds((const void*)c3conv_kernel<S, NB, TWB>, lds);
+    int per_cu = (int)(dev_info().lds_per_cu / (lds + 512));
     const int cap = NB <= 2 ? 4 : NB <= 4 ? 3 : 2;           // waves per SIMD the registers allow (kernel-resource-usage: 109 / 151 / 243 VGPRs)
     per_cu = per_cu < 1 ? 1 : per_cu > cap ? cap : per_cu;
-    int grid = 256 * per_cu;
+    int grid = dev_info().cus * per_cu;
     if (grid > P.ntiles) grid = P.ntiles;
     { const int rounds = (P.ntiles + grid - 1) / grid; grid = (P.ntiles + rounds - 1) / rounds; }     // whole rounds of tiles per block
     hipLaunchKernelGGL((c3conv_kernel<S, NB, TWB>), dim3((unsigned)grid), dim3(C3_THREADS), lds, s, P);

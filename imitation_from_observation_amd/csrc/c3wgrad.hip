@@ -217,8 +217,7 @@ void launch_w3(hipStream_t s, W3P P, int ngroups) {
     constexpr size_t tiles_b = (size_t)(((IH * IW * 4 + 3) & ~3) + 128 * CBP) * sizeof(float);
     constexpr size_t red_b = (size_t)2 * W3_RB * NB * 256 * sizeof(float);
     constexpr size_t lds = tiles_b > red_b ? tiles_b : red_b;
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)c3wgrad_kernel<S, NB, TWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+    ensure_dyn_lds((const void*)c3wgrad_kernel<S, NB, TWB>, lds);
     hipLaunchKernelGGL((c3wgrad_kernel<S, NB, TWB>), dim3((unsigned)(P.nbl * ngroups)), dim3(W3_THREADS), lds, s, P);
 }
 
@@ -244,7 +243,7 @@ void c3wgrad(hipStream_t s, const DcWgrad& D, float* slab, int64_t slab_floats) 
     W3P P{D.big, D.s1, D.ld1, D.c1, D.s2, D.ld2, D.nmod2 > 0 ? D.nmod2 : 1, D.nimg, D.hb, D.wb, D.hs, D.ws, D.hs / TH, D.ws / TW, 0, 0, slab, nullptr};
     P.ntiles = P.nimg * P.tiles_y * P.tiles_x;
     // persistent blocks: two per CU over all column groups, whole rounds of tiles per block, inside the slab
-    int64_t nbl = 512 / ngroups;
+    int64_t nbl = 2 * dev_info().cus / ngroups;
     const int64_t cap = slab_floats / ((int64_t)ngroups * 76 * NP);
     if (nbl > cap) nbl = cap;
     if (nbl > P.ntiles) nbl = P.ntiles;

@@ -240,10 +240,9 @@ void launch_ct3(hipStream_t s, Ct3 A, int TW) {
     A.tiles_x = (A.win + A.TW - 1) / A.TW;
     A.ntiles = A.nimg * A.tiles_y * A.tiles_x;
     const size_t lds = (size_t)((A.IH * A.IW * PS + 3) & ~3) * 4 + 25 * 4 * KS * 4;
-    if (A.IH * A.IW * KQ > NT * CT3_PF || lds > 160 * 1024) { set_launch_error("convt3: input tile %d x %d does not fit the prefetch slots / LDS", A.IH, A.IW); return; }
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)convt3_kernel<S, P, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
-    int per_cu = (int)((160 * 1024) / (lds + 1024));
+    if (A.IH * A.IW * KQ > NT * CT3_PF || lds > (size_t)dev_info().lds_per_cu) { set_launch_error("convt3: input tile %d x %d does not fit the prefetch slots / LDS", A.IH, A.IW); return; }
+    ensure_dyn_lds((const void*)convt3_kernel<S, P, NT>, lds);
+    int per_cu = (int)(dev_info().lds_per_cu / (lds + 1024));
     per_cu = per_cu < 1 ? 1 : per_cu > 2048 / NT ? 2048 / NT : per_cu;
     int grid = 256 * per_cu;
     if (grid > A.ntiles) grid = A.ntiles;

@@ -8,9 +8,10 @@
 namespace ctx {
 
 namespace {
-constexpr int LDS_TOTAL = 160 * 1024;       // per CU
-constexpr int LDS_BUDGET = 156 * 1024;      // one block of 8 waves
-constexpr int NUM_CU = 256;
+// per CU / one block of 8 waves / CUs: from the device (dev_info), MI355X: 160 KiB, 156 KiB, 256
+#define LDS_TOTAL (dev_info().lds_per_cu)
+#define LDS_BUDGET (dev_info().lds_per_cu - 4096)
+#define NUM_CU (dev_info().cus)
 
 int cik_of(int CI) { return CI == 3 ? 4 : CI <= 8 ? 8 : CI <= 16 ? 16 : CI <= 32 ? 32 : 64; }
 
@@ -23,14 +24,12 @@ void launch_fwd_one(hipStream_t s, const DcFwd& P, int occ, dim3 grid, size_t ld
     if constexpr ((NB == 1 && MI <= 4) || (NB == 2 && MI <= 3) || (NB == 4 && MI <= 2)) {
         if constexpr (MI * NB <= 2) {          // (MI x NB = 4 spills at 128 registers)
             if (occ == 2) {                                   // the two-blocks-per-CU build (<= 128 registers, 4 prefetch slots)
-                static bool raised2 = false;
-                if (!raised2) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, NB, DC_PF_SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL / 2); raised2 = true; }
+                ensure_dyn_lds((const void*)dconv_fwd_kernel<CIK, MI, NB, DC_PF_SMALL>, (size_t)LDS_TOTAL / 2);
                 hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, NB, DC_PF_SMALL>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);
                 return;
             }
         }
-        static bool raised = false;
-        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_fwd_kernel<CIK, MI, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; }
+        ensure_dyn_lds((const void*)dconv_fwd_kernel<CIK, MI, NB>, (size_t)LDS_TOTAL);
         hipLaunchKernelGGL((dconv_fwd_kernel<CIK, MI, NB>), grid, dim3(DC_THREADS), lds, s, P, ntiles, nslots);
     }
 }
@@ -249,8 +248,7 @@ template <int CAK, int RBW, int WM, int SS>
 void launch_wg_nb(hipStream_t s, const DcWgrad& P, int NB, dim3 grid, size_t lds) {
 #define DC_CASE(nb)                                                                                                          \
     case nb: {                                                                                                               \
-        static bool raised = false;                                                                                          \
-        if (!raised) { (void)hipFuncSetAttribute((const void*)dconv_wgrad_kernel<CAK, RBW, WM, nb, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL); raised = true; } \
+        ensure_dyn_lds((const void*)dconv_wgrad_kernel<CAK, RBW, WM, nb, SS>, (size_t)LDS_TOTAL);                                \
         hipLaunchKernelGGL((dconv_wgrad_kernel<CAK, RBW, WM, nb, SS>), grid, dim3(DC_THREADS), lds, s, P);                       \
         break;                                                                                                               \
     }

@@ -14,11 +14,7 @@ template <class LA, class LB, int MI, int NI, int WM, int WN>
 static void launch_tile_split(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int nsplit) {
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     constexpr size_t lds = 2 * (size_t)(STile<LA::KM, TM, NT>::FLOATS + STile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
-        (void)hipFuncSetAttribute((const void*)igemm_split_kernel<LA, LB, MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
-    }
+    if (lds > 65536) ensure_dyn_lds((const void*)igemm_split_kernel<LA, LB, MI, NI, WM, WN>, lds);
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
     int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
     if (nblk < 64) ep.xcd_swizzle = 0;
@@ -36,11 +32,7 @@ static void launch_tile_f32(hipStream_t s, const LA& a, const LB& b, Epi ep, int
     constexpr int NT = 64 * WM * WN, TM = 32 * MI * WM, TN = 32 * NI * WN;
     // two LDS stages of [A tile | B tile]; above the 64 KiB default the limit is raised once per kernel
     constexpr size_t lds = 2 * (size_t)(Tile<LA::KM, TM, NT>::FLOATS + Tile<LB::KM, TN, NT>::FLOATS) * sizeof(float);
-    static bool raised = false;
-    if (lds > 65536 && !raised) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<LA, LB, MI, NI, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        raised = true;
-    }
+    if (lds > 65536) ensure_dyn_lds((const void*)igemm_kernel<LA, LB, MI, NI, WM, WN>, lds);
     const int gm = (M + TM - 1) / TM, gn = (N + TN - 1) / TN;
     int64_t nblk = (int64_t)gm * gn * nprob * nsplit;
     if (nblk < 64) ep.xcd_swizzle = 0;
@@ -102,9 +94,9 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     if (min_chunks >= 8 && ws.slab) {
         const size_t lds = ws.prec ? 2 * (size_t)(64 * MI + 64 * NI) * SLDR * sizeof(float)
                                    : 2 * (size_t)((LA::KM ? 64 * MI * LDK : KC * 64 * MI) + (LB::KM ? 64 * NI * LDK : KC * 64 * NI)) * sizeof(float);
-        int occ = (int)(160 * 1024 / lds);
+        int occ = (int)(dev_info().lds_per_cu / lds);
         if (occ > (MI * NI == 4 ? 2 : 4)) occ = MI * NI == 4 ? 2 : 4;            // register-file limit
-        const double slots = 256.0 * occ;
+        const double slots = (double)dev_info().cus * occ;
         // `occ` waves share each SIMD's matrix pipe; the split-bf16 chunk is 6 x 32 cycles per 32x32 tile but
         // runs at about half the pipe rate (conversion + LDS traffic), so ~1/3 of the f32 chunk
         const double t_chunk = 16.0 * MI * NI * 64.0 * occ / 2.3e9 * (ws.prec ? 0.35 : 1.0);

@@ -1,10 +1,45 @@
 // kernels.hip -- the HBM-bound and small kernels around the implicit GEMMs: split-K combine,
 // conv2d_transpose to 3 channels, input preprocessing, losses, bias gradients, lrelu', Adam.
 #include <cstdarg>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdio>
 #include "launch.h"
 
 namespace ctx {
+
+const DevInfo& dev_info() {
+    static std::mutex mu;
+    static std::map<int, DevInfo> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find(dev);
+    if (it == cache.end()) {
+        hipDeviceProp_t pr{};
+        DevInfo d{256, 160 * 1024};                                // MI355X, should the query fail
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+            if (pr.multiProcessorCount > 0) d.cus = pr.multiProcessorCount;
+            if (pr.maxSharedMemoryPerMultiProcessor > 0) d.lds_per_cu = (int)pr.maxSharedMemoryPerMultiProcessor;
+        }
+        it = cache.emplace(dev, d).first;
+    }
+    return it->second;
+}
+
+void ensure_dyn_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, size_t> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    size_t& have = done[{kernel, dev}];
+    if (bytes > have) {
+        (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        have = bytes;
+    }
+}
 
 namespace { thread_local char g_launch_err[256]; thread_local bool g_launch_err_set = false; }
 void set_launch_error(const char* fmt, ...) {

@@ -14,6 +14,12 @@ namespace ctx {
 void set_launch_error(const char* fmt, ...);
 bool take_launch_error(char* buf, size_t n);       // true (and the message, cleared) if one is pending on this thread
 
+// The current device's CU count and LDS per CU (hipDeviceProp, cached per device id): what the launchers size persistent grids and
+// tiles with.  ensure_dyn_lds raises a kernel's dynamic-LDS limit once per (kernel, device) -- and again if a later launch needs more.
+struct DevInfo { int cus; int lds_per_cu; };
+const DevInfo& dev_info();
+void ensure_dyn_lds(const void* kernel, size_t bytes);
+
 // Split-K policy shared by all launchers: `slab` is scratch of `slab_floats` floats.
 struct SplitWs {
     float* slab;

@@ -425,8 +425,7 @@ static size_t rc_bwd_lds(int D0p) { return (size_t)(2 * RC_TB * (D0p + 4) + 2 * 
 void rchain_fwd(hipStream_t s, int B, int D0p, const float* a3, float* a4, float* Z, float* th0, float* dz, const float* const W[10]) {
     RcF P{B, D0p, a3, a4, Z, th0, dz, W[0], W[1], W[2], W[3], W[4], W[5], W[6], W[7], W[8], W[9]};
     const size_t lds = rc_fwd_lds(D0p);
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)rchain_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+    ensure_dyn_lds((const void*)rchain_fwd_kernel, lds);
     hipLaunchKernelGGL(rchain_fwd_kernel, dim3((unsigned)((B + RC_TB - 1) / RC_TB)), dim3(RC_T), lds, s, P);
 }
 
@@ -434,8 +433,7 @@ void rchain_bwd(hipStream_t s, int B, int D0p, const float* dDz, const float* ds
                 const float* th0, const float* a4, const float* a3, const float* dSk3, const float* const W[10]) {
     RcB P{B, D0p, dDz, dsim2, dZ, dth0, dA4, dA3, Z, th0, a4, a3, dSk3, W[0], W[2], W[4], W[6], W[8]};
     const size_t lds = rc_bwd_lds(D0p);
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)rchain_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+    ensure_dyn_lds((const void*)rchain_bwd_kernel, lds);
     hipLaunchKernelGGL(rchain_bwd_kernel, dim3((unsigned)((B + RC_TB - 1) / RC_TB)), dim3(RC_T), lds, s, P);
 }
 

@@ -342,10 +342,11 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
     // Measured (B = 256, whole step, three runs each): splitting the 4x4 launches makes THEM faster when timed alone (d_h1 forward 0.82 ->
     // 0.78 ms, conv_context h3 dx 0.31 -> 0.23) but the step no faster (13.75 vs 13.72 ms): they share the chip with the side lanes, and the
     // slabs + reduce launches take from those.  So the default is no split (narrower column tiles instead); CTX_WCONVT_KSGRID=16 turns it on.
+    const int slots400 = dev_info().cus * 2 * 25 / 32;                     // ~ 78 % of the resident block slots (400 of 512 on MI355X)
     static const int ks_grid = [] { const char* e = getenv("CTX_WCONVT_KSGRID"); return e ? atoi(e) : 0; }();    // largest grid (positions) that may split
-    while (hs * ws <= ks_grid && ks < ks_max && ntile * (ca / (nb2 ? 64 : 32)) * ks < 400 && nsl / (2 * ks) >= 4 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
+    while (hs * ws <= ks_grid && ks < ks_max && ntile * (ca / (nb2 ? 64 : 32)) * ks < slots400 && nsl / (2 * ks) >= 4 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
     if (force_ks) ks = force_ks;
-    if (ks == 1 && nb2 && !force_nb && ntile * (ca / 64) < 400) nb2 = false;        // no room to split: narrower column tiles instead
+    if (ks == 1 && nb2 && !force_nb && ntile * (ca / 64) < slots400) nb2 = false;        // no room to split: narrower column tiles instead
     P.gn = nb2 ? ca / 64 : ca / 32;
     P.ksplit = ks;
     P.slab = ks > 1 ? wsp.slab : nullptr;
