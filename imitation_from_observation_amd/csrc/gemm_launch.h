@@ -71,7 +71,7 @@ static void launch_128(hipStream_t s, const LA& a, const LB& b, const Epi& ep, i
 
 template <class LA, class LB, bool BIG = false, int W32 = 1, int WSP = 0>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
-                         SplitWs ws) {
+                         SplitWs ws, int max_chunks = 0) {
     static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
     if constexpr (BIG) {
         const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
@@ -104,8 +104,24 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         double best = 1e30;
         for (int n = 1; n <= 256 && n <= min_chunks / 4 && (n == 1 || n <= cap_ws); ++n) {
             const double rounds = std::ceil(tiles * n / slots);
-            double t = rounds * ((min_chunks + n - 1) / n + 6) * t_chunk;
-            if (n > 1) t += 2.0 * n * nprob * (double)M * N * 4 / 3e12 + 4e-6;   // slab out + in, + the combine launch
+            double len = rounds * ((min_chunks + n - 1) / n + 6);
+            // problems of unequal length (the rectangle-ordered filter gradient: border taps see 9/16 of a 4x4 grid's pixels, `min_chunks`
+            // is their MEAN): a launch cannot end before its longest block, which one round of blocks does not average away -- without
+            // this term d_h1's filter gradient (400 tiles, one round, 144..256 chunks per block) ran unsplit at the pace of its
+            // longest tap (0.87 ms)
+            // ... and yet it is OFF (CTX_SPLIT_MAXTERM=1 turns it on): with it d_h1's filter gradient takes 0.70 ms instead of 0.87 alone
+            // (154 TF/s) and the three launches it changes save 0.24 ms serialised, but the STEP gets 0.1 ms longer (three A/B pairs on one
+            // box: 13.37 / 13.39 / 13.41 without, 13.47 / 13.48 / 13.51 with).  The unsplit launch's idle CUs are not idle in a step --
+            // the other lanes' kernels run there -- while the split adds slab traffic and a combine launch: work, which the step pays.
+            static const bool maxterm = [] { const char* e = getenv("CTX_SPLIT_MAXTERM"); return e && e[0] == '1'; }();
+            if (maxterm && max_chunks > min_chunks) { const double longest = (max_chunks + n - 1) / n + 6; if (longest > len) len = longest; }
+            double t = len * t_chunk;
+            // slab out + in, + the combine launch.  Weight (CTX_SPLIT_SLABW): in the exact-f32 mode a quarter of the estimate -- measured
+            // on whole steps, not launches: 1, 0.7, 0.5 and 0.25 give the same step (13.45-13.49 ms) while 0.25 takes 0.19 ms off the
+            // filter-gradient launches run alone; 2, 4, 8 cost +0.05, +0.15, +0.3 ms of step.  The split-bf16 mode keeps 1 (0.25: +0.1 ms).
+            static const double slabw_env = [] { const char* e = getenv("CTX_SPLIT_SLABW"); return e ? atof(e) : 0.0; }();
+            const double slabw = slabw_env > 0.0 ? slabw_env : ws.prec ? 1.0 : 0.25;
+            if (n > 1) t += slabw * (2.0 * n * nprob * (double)M * N * 4 / 3e12 + 4e-6);
             if (t < best * 0.97) { best = t; nsplit = n; }                        // prefer fewer splits on near-ties
         }
     }

@@ -21,14 +21,20 @@ static int rect_avg_chunks(const RectGeo& g) {
         for (int kx = 0; kx < g.K; ++kx) t += (int64_t)g.rh[ky] * g.rw[kx] * g.ipc;
     return (int)(t / (g.K * g.K));
 }
+static int rect_max_chunks(const RectGeo& g) {
+    int64_t t = 0;
+    for (int ky = 0; ky < g.K; ++ky)
+        for (int kx = 0; kx < g.K; ++kx) { const int64_t c = (int64_t)g.rh[ky] * g.rw[kx] * g.ipc; if (c > t) t = c; }
+    return (int)t;
+}
 int xcd_swz();
 void conv_wgrad_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmallR& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
-    launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
+    launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g));
 }
 void conv_wgrad2_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmall2R& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
-    launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws);
+    launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g));
 }
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;
