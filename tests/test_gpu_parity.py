@@ -65,7 +65,9 @@ def load_golden(path):
 # ------------------------------------------------------------------------------- vs the oracle
 @pytest.mark.parametrize("H,W,d,F,B", [(32, 32, 32, 128, 4), (16, 48, 32, 128, 3), (48, 48, 32, 64, 2), (16, 16, 32, 32, 1),
                                        (32, 32, 64, 256, 5),
-                                       (64, 128, 32, 64, 2)])      # 64-wide small grid: the 64-column tiles of convt3 / dconv, two tiles per row
+                                       (64, 128, 32, 64, 2),       # 64-wide small grid: the 64-column tiles of convt3 / dconv, two tiles per row
+                                       (16, 16, 96, 32, 2)])       # df_dim 96: d_h4's input gradient has 192 columns, past what the narrow-channel
+                                                                   # direct kernels pack -- the handle must stay on the kernels that cover it
 def test_forward_backward_matches_oracle(T, H, W, d, F, B):
     cfg, p, fr = make_case(H, W, d, F, B)
     src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
