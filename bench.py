@@ -353,6 +353,12 @@ def main():
     if os.environ.get("BENCH_SPAWN_SELFTEST") == "1":
         return spawn_selftest(args)
 
+    # stdout carries ONE line, rank 0's JSON: file descriptor 1 is pointed at stderr for the run (librccl prints a version banner to
+    # stdout at communicator creation, torch.distributed warns there too) and the saved descriptor gets the line at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from imitation_from_observation_amd.dp import DataParallelTrainer, RcclTrainer
@@ -377,7 +383,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
 
     B = args.batch
-    # N > 1: the data-parallel step behind the C ABI (ctx_dp_train_step: RCCL inside libctxtrans, two gradient buckets, the tail
+    # N > 1: the data-parallel step behind the C ABI (ctx_dp_train_step: RCCL inside libctxtrans, gradient buckets sent from inside backward, the tail
     # bucket reduced on a second stream under the encoders' backward) -- torch.distributed only ships the 128-byte rendezvous blob
     # and does the contract's barrier / max-over-ranks.  BENCH_DP=torch selects the torch.distributed client of the same step
     # (dp.DataParallelTrainer: one all-reduce after backward, or the bucketed schedule with CTX_DP_OVERLAP=1).
@@ -454,7 +460,7 @@ def main():
                                  "split-bf16: a*b = hi*hi + hi*lo + lo*hi on bf16 MFMA, f32 accumulate; f32 everywhere else"),
                    "per_gpu_batch": B, "global_batch": B * world, "params": trainer.n_params,
                    "parallelism": f"dp{world}" + (" + RCCL grad all-reduce" if world > 1 else ""),
-                   "dp_client": {"cabi": "ctx_dp_train_step (RCCL behind the C ABI, two buckets, second stream)",
+                   "dp_client": {"cabi": "ctx_dp_train_step (RCCL behind the C ABI; buckets from inside backward: translate+decoder, each encoder's FC slice; conv filters last; second stream)",
                                  "torch": "torch.distributed all-reduce between ctx_dev_forward_backward and ctx_dev_adam",
                                  "single": "none (one rank)"}[dp_client]},
         "loss_after": scal["loss"],
@@ -598,7 +604,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(batch=32, steps=10)
         import ctypes
         ctypes.CDLL(None).fflush(None)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -123,7 +123,8 @@ struct ctx_handle {
     float* dp_scal = nullptr;
     bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
     int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
-    int dp_rc = 0;                // result of the tail bucket's collective (started from inside backward)
+    int dp_rc = 0;                // result of the collectives started from inside backward
+    std::vector<std::pair<int64_t, int64_t>> dp_done;   // [first, end) of the HEAD of the arena already sent in this step (the encoders' FC slices)
     // Adam beside the backward (fused training steps only: adam_begin / adam_early / adam_end): a slice of the arena is updated on
     // its own stream as soon as its gradients are final and its parameters have been read for the last time in this step
     hipStream_t adam_stream = nullptr;
@@ -499,6 +500,20 @@ void fire_bucket(ctx_handle* h, int64_t first) {
     h->bucket_fn(h->bucket_user, 0, first, h->Ppad - first);
 }
 
+// ctx_dp_train_step, inside the encoders' backward: gradients [first, end) -- an encoder's h4_lin / hz_lin, two thirds of its
+// parameters -- are final in the order of the CURRENT stream plus (lane >= 0) that side lane: their all-reduce starts now, behind
+// the tail bucket on the collective stream, instead of waiting for the convolutions' filter gradients.  What is left for the end
+// of the step are the encoders' conv filters (2 x 4.3 M of 47.6 M floats).  Same order of collectives on every rank (program order).
+void dp_bucket(ctx_handle* h, int64_t first, int64_t end, int lane) {
+    if (!h->dp_in_step || h->dp_rc != CTX_OK || first < 0 || end <= first) return;
+    if (lane >= 0 && use_lanes(h)) {
+        (void)hipEventRecord(h->ev_join[lane], h->aux[lane]);
+        (void)hipStreamWaitEvent(h->dp_stream, h->ev_join[lane], 0);
+    }
+    h->dp_rc = dp_reduce_range(h, first, end - first);
+    h->dp_done.emplace_back(first, end);
+}
+
 const char* const K_CONV = "igemm<ConvGather,Plain>";
 const char* const K_CONVT = "igemm<ConvTGather,ConvTWeights>";
 const char* const K_CONVT1 = "igemm<ConvGather,ConvTWeights>";   // stride-1 conv2d_transpose as a flipped correlation (convt1_fwd)
@@ -823,9 +838,10 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         e3.out1 = dA[3]; e3.ld1 = K3; e3.mask = act[3]; e3.ldm = K3;
         if (with_skips) { e3.add1 = h->dSk[3]; e3.lda1 = K3; e3.add2 = h->dSk[3] + (int64_t)B * K3; e3.lda2 = K3; }
         fc_dx(h, scn + "/h4_lin", dA[4], nimg, F, sc.w4, K3, e3);
-        if (!h->bucket_fn && !h->dp_in_step) {   // h4_lin / hz_lin of this encoder (2/3 of its parameters) are done with
-            const int64_t lin0 = h->find((scn + "/h4_lin/Matrix").c_str());
-            adam_early(h, lin0, lin0 + (int64_t)K3 * F + F + (int64_t)F * F + F, dw_lane);
+        {   // h4_lin / hz_lin of this encoder (2/3 of its parameters) are done with
+            const int64_t lin0 = h->find((scn + "/h4_lin/Matrix").c_str()), lin1 = lin0 + (int64_t)K3 * F + F + (int64_t)F * F + F;
+            if (h->dp_in_step) dp_bucket(h, lin0, lin1, dw_lane);
+            else if (!h->bucket_fn) adam_early(h, lin0, lin1, dw_lane);
         }
         for (int k = 3; k >= 0; --k) {
             const int hb = h->hh[k], wb = h->ww[k], hs = hb / 2, wsm = wb / 2;
@@ -1698,13 +1714,21 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     forward(h, B, MODE_TRAIN);
     // two buckets: [split, Ppad) = translate/* + deconv/* leaves from inside backward (fire_bucket) and travels while the
     // encoders' backward runs; [0, split) = the encoders after it.  simloss is a mean over the GLOBAL batch (arm_shaping.py:1345).
-    h->dp_in_step = true; h->dp_split = -1; h->dp_rc = CTX_OK;
+    h->dp_in_step = true; h->dp_split = -1; h->dp_rc = CTX_OK; h->dp_done.clear();
     backward(h, B, B * h->dp_world);
     h->dp_in_step = false;
     h->drop_on = false;
     TRY(h->dp_rc);
     const int64_t split = h->dp_split >= 0 ? h->dp_split : h->Ppad;
-    TRY(dp_reduce_range(h, 0, split));
+    {   // what the buckets sent from inside backward left of the head [0, split)
+        std::sort(h->dp_done.begin(), h->dp_done.end());
+        int64_t at = 0;
+        for (size_t i = 0; i <= h->dp_done.size(); ++i) {
+            const int64_t stop = i < h->dp_done.size() ? h->dp_done[i].first : split;
+            if (stop > at) TRY(dp_reduce_range(h, at, stop - at));
+            if (i < h->dp_done.size()) at = h->dp_done[i].second;
+        }
+    }
     TRY(dp_wait(h));
     TRY(adam_step(h, lr));
     h->last_B = B;

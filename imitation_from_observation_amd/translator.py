@@ -464,7 +464,7 @@ class Translator:
 
     def dp_train_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4, scalars=False):
         """One data-parallel step on this rank's shard (device addresses of f32 [B,H,W,3]): forward, backward with the simloss
-        mean over the global batch, two-bucket all-reduce overlapped with the encoders' backward, Adam.  scalars=True also
+        mean over the global batch, bucketed all-reduce overlapped with the encoders' backward (translate + decoder, then each encoder's FC slice, the conv filters last), Adam.  scalars=True also
         returns the GLOBAL dict(loss, simloss, recon1, recon2) (one more tiny collective + a sync)."""
         sc = np.empty(4, np.float32) if scalars else None
         self._ck(self._lib.ctx_dp_train_step(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt), B,

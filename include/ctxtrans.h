@@ -247,8 +247,9 @@ int ctx_last_codes(ctx_handle* h, float* input_z, float* translated_z, int* B);
  *                         and Adam slots so the replicas start identical
  *   ctx_dp_allreduce_grads  the exchange step alone: in-place SUM all-reduce of the gradient arena, stream-ordered between
  *                         ctx_dev_forward_backward(sim_batch = B * world) and ctx_dev_adam (asynchronous)
- *   ctx_dp_train_step     the whole step with the two-bucket schedule: the translate/deconv gradients are reduced on a second
- *                         stream while the encoders' backward runs, the encoders' after it; then Adam.  scalars (nullable) =
+ *   ctx_dp_train_step     the whole step with the bucketed schedule: the translate/deconv gradients, then each encoder's
+ *                         h4_lin / hz_lin slice, are reduced on a second stream while the encoders' backward still runs;
+ *                         only the encoders' conv filters (18 % of the arena) go after it; then Adam.  scalars (nullable) =
  *                         GLOBAL {loss, simloss, recon1, recon2} (one more 16-byte all-reduce and a sync).  d_* are DEVICE
  *                         pointers [B,H,W,3] f32; every rank passes the same B.
  *   ctx_dp_scalars        global scalars of the last forward (collective) */
