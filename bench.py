@@ -389,6 +389,19 @@ def main():
     # (dp.DataParallelTrainer: one all-reduce after backward, or the bucketed schedule with CTX_DP_OVERLAP=1).
     dp_client = os.environ.get("BENCH_DP", "cabi") if dist.is_initialized() else "single"
     if dp_client == "cabi":
+        # every rank must take the same client: agree first that librccl loads everywhere behind the C ABI (else the torch client)
+        try:
+            from imitation_from_observation_amd import Translator as _T
+            _T.dp_unique_id()
+            ok = 1
+        except Exception as e:                                  # noqa: BLE001  (a missing / unloadable librccl on this rank)
+            sys.stderr.write(f"bench.py: rank {rank}: RCCL behind the C ABI unavailable ({e!r}); asking for the torch client\n")
+            ok = 0
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            dp_client = "torch"
+    if dp_client == "cabi":
         trainer = RcclTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, rank=rank, world=world, precision=args.precision)
     else:
         trainer = DataParallelTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, precision=args.precision)
