@@ -545,21 +545,24 @@ KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nul
 
 // ContextSkipNew's 3-channel edge layers (h0_conv forward / filter gradient, d_h4's input and filter gradients) on the direct
 // kernels of dconv.h: the frames and d loss / d out are read as they are ([pixel][3]), so the 4-channel copies and their pack
-// passes go away.  ON by default in the exact-f32 mode (the split-bf16 mode keeps the implicit GEMM on its 4-channel copies):
+// passes go away.  ON by default, in both precisions since the end of round 3 (the split-bf16 mode used to keep the implicit GEMM on 4-channel copies):
 // measured on the persistent / prefetching dconv kernels 0.99 -> 0.71 ms of layer time per step.  CTX_DCONV_C3=0 restores the
 // implicit GEMM.  The direct forward kernel packs at most 128 filter columns (dconv_ok): d_h4's input gradient has N = 2 * df_dim
 // columns, so a handle with df_dim > 64 stays on the implicit GEMM for all of its 3-channel layers (decided per handle, because
 // the implicit GEMM needs the 4-channel copies refreshed by forward / backward).
 bool use_dc3(const ctx_handle* h) {
     static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return !(e && e[0] == '0'); }();
-    return on && h->cfg.precision == CTX_PREC_F32 && dconv_ok(3, h->d) && dconv_ok(3, 2 * h->d);
+    // (both precisions: the seven 3-channel launches are 1 % of the step's FLOPs, and their exact-f32 direct kernels are faster than the
+    // split-bf16 implicit GEMM on 4-channel copies -- 0.8 ms against 1.5 ms of the split-bf16 step -- and more accurate)
+    return on && dconv_ok(3, h->d) && dconv_ok(3, 2 * h->d);
 }
 
 // d_h4 (conv2d_transpose to the 3 image channels) in one pass on the vector ALUs (convt3.hip) instead of scatter product + gather.
-// Exact-f32 mode only.  CTX_CONVT3_DIRECT=0 restores the two-step route (and its P3 buffer).
+// ContextSkipNew: both precisions (exact f32 arithmetic either way); the table-driven models: exact-f32 mode only.
+// CTX_CONVT3_DIRECT=0 restores the two-step route (and its P3 buffer).
 bool d_h4_direct(const ctx_handle* h, int c1, int c2, int hs, int ws, int stride) {
     static const bool on = [] { const char* e = getenv("CTX_CONVT3_DIRECT"); return !(e && e[0] == '0'); }();
-    return on && h->cfg.precision == CTX_PREC_F32 && convt3_direct_ok(c1, c2, hs, ws, stride);
+    return on && (h->cfg.precision == CTX_PREC_F32 || !h->gen) && convt3_direct_ok(c1, c2, hs, ws, stride);
 }
 bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
 
