@@ -889,7 +889,8 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add1 = h->dSk[k - 1]; ed.lda1 = ca;
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
-            const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, wsm, cb, 0, ca);
+            // (split-bf16 mode: the exact-f32 kernel only where it is the faster one -- the 16x16 grids' few-channel input gradients)
+            const bool wide = (h->cfg.precision == CTX_PREC_F32 || hs == 16) && wconvt_ok(hs, wsm, cb, 0, ca);
             ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl);
             if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed, ws_of(h));
             else if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
