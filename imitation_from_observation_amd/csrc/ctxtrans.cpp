@@ -1775,7 +1775,11 @@ int ctx_dp_scalars(ctx_handle* h, float scalars[4]) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->dp_world > 1) {                         // (a one-rank sum is the identity: the device's own f64-accumulated loss stands)
         s[1] /= (float)h->dp_world;
-        s[0] = (float)((double)s[1] + (double)s[2] + (double)s[3]);
+        // `loss` = what Adam minimises: only the terms ctx_config.loss_terms keeps (ablations_code/ablations.py:175-182), like the
+        // loss kernel's own masking of scalars[0] on one rank
+        const int terms = loss_terms_of(h);
+        s[0] = (float)((terms & CTX_LOSS_SIM ? (double)s[1] : 0.0) + (terms & CTX_LOSS_RECON1 ? (double)s[2] : 0.0) +
+                       (terms & CTX_LOSS_RECON2 ? (double)s[3] : 0.0));
     }
     memcpy(scalars, s, sizeof s);
     return CTX_OK;

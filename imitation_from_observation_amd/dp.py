@@ -145,7 +145,9 @@ class DataParallelTrainer:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t[1] /= self.world                               # simloss: mean over equal shards
-            t[0] = t[1] + t[2] + t[3]
+            # `loss` = the terms Adam minimises (ctx_config.loss_terms; ablations_code/ablations.py:175-182)
+            terms = int(getattr(getattr(self.translator, "cfg", None), "loss_terms", 0) or 0) or 7
+            t[0] = (t[2] if terms & 1 else 0) + (t[3] if terms & 2 else 0) + (t[1] if terms & 4 else 0)
         v = [float(x) for x in t.cpu()]
         return dict(loss=v[0], simloss=v[1], recon1=v[2], recon2=v[3])
 

@@ -16,9 +16,11 @@ from .translator import Translator
 
 class InceptionTranslator:
     def __init__(self, imsize=(125, 125), max_batch=25, device=0, precision=None, df_dim=64, featsize=1024, stream=None,
-                 strides=None, kernels=None, filters=None):
-        # the front end sees src + ctx (+ tgt when training) frames of one batch in a single pass
-        self.front = InceptionFrontend(imsize[0], imsize[1], max_images=3 * max_batch, device=device,
+                 strides=None, kernels=None, filters=None, train=True):
+        # the front end sees src + ctx (+ tgt when training) frames of one batch in a single pass: 3 * max_batch images for the
+        # trainer, 2 * max_batch for the reward hook (train=False: translate = B + B, encode = B), which sizes every activation buffer
+        self.train = bool(train)
+        self.front = InceptionFrontend(imsize[0], imsize[1], max_images=(3 if train else 2) * max_batch, device=device,
                                        precision=precision or "f32", stream=stream)
         h, w, c = self.front.out_shape
         self.tr = Translator(h, w, df_dim, featsize, max_batch=max_batch, device=device, variant="inception2", C=c,
@@ -57,6 +59,9 @@ class InceptionTranslator:
 
     def _triple_dev(self, src, ctx, tgt):
         B = len(src)
+        if 3 * B > self.front.max_images:
+            raise ValueError(f"{B} triples need {3 * B} front-end images, the handle holds {self.front.max_images}"
+                             + ("" if self.train else " (built with train=False: the reward hook's two fetches only)"))
         d = self.front.features_u8_dev(np.concatenate([src, ctx, tgt]))
         return d, d + B * self._per, d + 2 * B * self._per, B
 

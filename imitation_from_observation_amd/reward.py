@@ -39,7 +39,7 @@ class TranslatorReward:
         from .translator import Translator
         if mode == "oursinception":
             from .oursinception import InceptionTranslator
-            it = InceptionTranslator(imsize, max_batch=batch_size * paths_per_launch, device=device)
+            it = InceptionTranslator(imsize, max_batch=batch_size * paths_per_launch, device=device, train=False)
             if inception_ckpt is not None:
                 it.front.load(inception_ckpt)
             if modelname is not None:

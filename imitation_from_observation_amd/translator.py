@@ -473,7 +473,7 @@ class Translator:
             return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
     def dp_world(self):
-        """(rank, world) of this handle's RCCL group; (0, 1) before dp_init."""
+        """(rank, world) of this handle's RCCL group; (0, 0) before dp_init (ctx_dp_world reports world 0 until a group exists)."""
         r, w = ctypes.c_int(0), ctypes.c_int(1)
         self._ck(self._lib.ctx_dp_world(self._h, ctypes.byref(r), ctypes.byref(w)))
         return int(r.value), int(w.value)

@@ -169,7 +169,8 @@ int ctx_train_step(ctx_handle* h, const float* src, const float* ctx, const floa
  * ctx_dev_forward_backward, ctx_dp_train_step).  The factor of element e at dropout site s in the step that follows `t` Adam updates
  * is  (hash32(seed, t, s, e) < keep_prob * 2^32) / keep_prob  -- a counter-based hash (csrc/kernels.hip: drop_hash) that
  * oracle/ctx_oracle_real.py restates, so a step can be checked with the masks it used.  Default seed 0.  (TensorFlow's own random
- * stream is not reproducible from outside; tf.nn.dropout's arithmetic x * mask / keep_prob is.) */
+ * stream is not reproducible from outside; tf.nn.dropout's arithmetic x * mask / keep_prob is.)  After ctx_dp_init rank r hashes with
+ * seed ^ (0x9E3779B9 * r), so the shards of a data-parallel batch draw different masks (rank 0 keeps the single-device masks). */
 int ctx_set_dropout_seed(ctx_handle* h, uint64_t seed);
 /* Same on uint8 frames, preprocessed on device with (x/255 - 0.5)*2. */
 int ctx_train_step_u8(ctx_handle* h, const uint8_t* src, const uint8_t* ctx, const uint8_t* tgt,
@@ -256,7 +257,7 @@ int ctx_last_codes(ctx_handle* h, float* input_z, float* translated_z, int* B);
 #define CTX_DP_UNIQUE_ID_BYTES 128
 int ctx_dp_unique_id(uint8_t id[CTX_DP_UNIQUE_ID_BYTES]);
 int ctx_dp_init(ctx_handle* h, const uint8_t id[CTX_DP_UNIQUE_ID_BYTES], int rank, int world);
-int ctx_dp_world(const ctx_handle* h, int* rank, int* world);   /* world = 0 before ctx_dp_init */
+int ctx_dp_world(const ctx_handle* h, int* rank, int* world);   /* (rank 0, world 0) before ctx_dp_init */
 int ctx_dp_allreduce_grads(ctx_handle* h);
 int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr,
                       float scalars[4]);

@@ -184,8 +184,9 @@ def _decode(p, cfg, z, skips):
     return hs, cats
 
 
-def forward(p, src, ctx, tgt, cfg: Incep2Config):
-    """src/ctx/tgt: feature maps [B,h,w,C] (image[0], image[1], image[2], :1798-1800)."""
+def forward(p, src, ctx, tgt, cfg: Incep2Config, ablation_type="None"):
+    """src/ctx/tgt: feature maps [B,h,w,C] (image[0], image[1], image[2], :1798-1800).  ablation_type: the loss switch every model
+    class of the ablation script carries (ablations_code/ablations.py:175-182): which terms make up `loss`."""
     c = {"src": src, "ctx": ctx, "tgt": tgt}
     c["e_ctx"] = _encode(p, "conv_context", ctx, cfg)
     c["e_src"] = _encode(p, "conv", src, cfg)
@@ -201,7 +202,9 @@ def forward(p, src, ctx, tgt, cfg: Incep2Config):
     res = {"input_z": src_z, "translated_z": c["trans_z"], "out": out, "out2": out2,
            "simloss": np.mean((c["trans_z"] - tgt_z) ** 2) * 1e3,                       # :1882
            "recon1": 0.5 * np.sum((tgt - out) ** 2), "recon2": 0.5 * np.sum((tgt - out2) ** 2)}
-    res["loss"] = res["recon1"] + res["recon2"] + res["simloss"]
+    from .ctx_oracle import LOSS_ABLATIONS
+    res["loss"] = sum(res[t] for t in LOSS_ABLATIONS[ablation_type])                    # :1894 / ablations.py:175-182
+    c["ablation_type"] = ablation_type
     return res, c
 
 
@@ -212,7 +215,10 @@ def backward(p, c, cfg: Incep2Config, sim_batch=None):
     tgt, ctx = c["tgt"], c["ctx"]
     B, F = tgt.shape[0], cfg.featsize
     tgt_z = c["e_tgt"][5]
-    dsim = (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)
+    from .ctx_oracle import LOSS_ABLATIONS
+    terms = LOSS_ABLATIONS[c.get("ablation_type", "None")]
+    w1, w2 = float("recon1" in terms), float("recon2" in terms)
+    dsim = ("simloss" in terms) * (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)
 
     def acc(name, val):
         g[name] = val if g[name] is None else g[name] + val
@@ -234,8 +240,8 @@ def backward(p, c, cfg: Incep2Config, sim_batch=None):
             dskips[4 - k], dh = dcat[..., Cd:], dcat[..., :Cd]
         return lrelu_grad(hs[0], dh.reshape(B, -1)), dskips
 
-    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] + ctx - tgt)
-    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] + ctx - tgt)
+    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], w1 * (c["d1"][4] + ctx - tgt))
+    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], w2 * (c["d2"][4] + ctx - tgt))
     dtrans_z = lin_bwd("deconv/d_h0_lin", c["trans_z"], dz1_) + dsim
     dtgt_z = lin_bwd("deconv/d_h0_lin", tgt_z, dz2_) - dsim
     dth0 = lrelu_grad(c["trans_h0"], lin_bwd("translate/trans_z", c["trans_h0"], dtrans_z))

@@ -156,8 +156,10 @@ def _decode(p, cfg, z, skips, m5=None, m6=None):
     return hs, cats
 
 
-def forward(p, src, ctx, tgt, cfg: RealConfig, drop=None):
-    """drop: None (keep_prob = 1, the sampler's and the validation graph) or the dict of drop_masks()."""
+def forward(p, src, ctx, tgt, cfg: RealConfig, drop=None, ablation_type="None"):
+    """drop: None (keep_prob = 1, the sampler's and the validation graph) or the dict of drop_masks().  ablation_type: the loss
+    switch of the ablation script's copies of this class (ContextAEPushReal / ContextAESweep, ablations_code/ablations.py:175-182,
+    :477-484): which terms make up `loss`."""
     B = src.shape[0]
     d = drop or {}
     rows = {"tgt": slice(0, B), "src": slice(B, 2 * B), "ctx": slice(2 * B, 3 * B)}            # the library's encoder batch order
@@ -179,16 +181,21 @@ def forward(p, src, ctx, tgt, cfg: RealConfig, drop=None):
     res = {"input_z": src_z, "translated_z": c["trans_z"], "out": out, "out2": out2,
            "simloss": np.mean((c["trans_z"] - tgt_z) ** 2) * 1e3,          # :1676
            "recon1": 0.5 * np.sum((tgt - out) ** 2), "recon2": 0.5 * np.sum((tgt - out2) ** 2)}
-    res["loss"] = res["recon1"] + res["recon2"] + res["simloss"]
+    from .ctx_oracle import LOSS_ABLATIONS
+    res["loss"] = sum(res[t] for t in LOSS_ABLATIONS[ablation_type])       # :1684 / ablations.py:175-182, :477-484
+    c["ablation_type"] = ablation_type
     return res, c
 
 
 def backward(p, c, cfg: RealConfig, sim_batch=None):
+    from .ctx_oracle import LOSS_ABLATIONS
     g = OrderedDict((n, None) for n, _ in param_specs(cfg))
     tgt = c["tgt"]
     B, F = tgt.shape[0], cfg.featsize
     tgt_z = c["e_tgt"][5]
-    dsim = (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)
+    terms = LOSS_ABLATIONS[c.get("ablation_type", "None")]
+    w1, w2 = float("recon1" in terms), float("recon2" in terms)
+    dsim = ("simloss" in terms) * (2e3 / ((sim_batch or B) * F)) * (c["trans_z"] - tgt_z)
 
     def acc(name, val):
         g[name] = val if g[name] is None else g[name] + val
@@ -214,8 +221,8 @@ def backward(p, c, cfg: RealConfig, sim_batch=None):
         return lrelu_grad(hs[0], mul(dh.reshape(B, -1), 6, sl)), dskips
 
     p1, p2 = slice(0, B), slice(B, 2 * B)
-    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], c["d1"][4] - tgt, p1)
-    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], c["d2"][4] - tgt, p2)
+    dz1_, dsk1 = decode_bwd(c["d1"], c["d1_cats"], w1 * (c["d1"][4] - tgt), p1)
+    dz2_, dsk2 = decode_bwd(c["d2"], c["d2_cats"], w2 * (c["d2"][4] - tgt), p2)
     dtrans_z = mul(lin_bwd("deconv/d_h0_lin", c["d1_cats"][0], dz1_), 5, p1) + dsim      # simloss sees the un-dropped codes
     dtgt_z = mul(lin_bwd("deconv/d_h0_lin", c["d2_cats"][0], dz2_), 5, p2) - dsim
     dth0 = lrelu_grad(c["trans_h0"], mul(lin_bwd("translate/trans_z", c["trans_h0_d"], dtrans_z), 4, slice(0, B)))

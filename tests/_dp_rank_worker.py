@@ -99,6 +99,30 @@ def main():
         out["solo_imgs"] = np.stack(h1.imgs)
         solo.close()
     trw.close()
+    # (d) the ablation script's loss switch under data parallelism (ablations_code/ablations.py:175-182; ctx_config.loss_terms): "L1" =
+    # recon2 + simloss.  The GLOBAL `loss` must be made of those terms only (ctx_dp_scalars), the reduced gradient theirs.
+    tra = Translator(H, W, D, F, max_batch=SHARD, ablation_type="L1")
+    tra.set_params(p)
+    idfile3 = os.path.join(work, "uid3.bin")
+    if rank == 0:
+        uid3 = Translator.dp_unique_id()
+        with open(idfile3 + ".tmp", "wb") as f:
+            f.write(uid3)
+        os.rename(idfile3 + ".tmp", idfile3)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile3):
+            if time.time() - t0 > 60:
+                raise SystemExit("rank 0 never published the third unique id")
+            time.sleep(0.01)
+        uid3 = open(idfile3, "rb").read()
+    tra.dp_init(uid3, rank, world)
+    sc = tra.dp_train_step(ptr[0], ptr[1], ptr[2], SHARD, lr=0.0, scalars=True)
+    out["abl_scalars"] = np.array([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]], np.float64)
+    out["abl_scalars_again"] = np.array(list(tra.dp_scalars().values()), np.float64)
+    tra.sync()
+    out["abl_grads"] = tra.get_grads_flat()
+    tra.close()
     np.savez(os.path.join(work, f"rank{rank}.npz"), **out)
     tr.close()
     print(f"rank {rank} ok", flush=True)

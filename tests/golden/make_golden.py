@@ -311,3 +311,114 @@ def make_b256(chunk=16):
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "b256":
     make_b256()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Mode 'oursinception' at the REFERENCE's own size: 299x299 frames (sandbox/andrew/run_trpo_strike.py:84,
+# run_train_strike_inception.py:39-43: idims=(299, 299), batch_size=25) -> Inception-v3 Mixed_7c 8x8x2048
+# (rllab/sampler/base.py:121-132, nets/inception_v3_test.py:45-54) -> ContextAEInception2(strides [1,2,1,2], kernels [3,3,3,3],
+# filters [1024,1024,512,512]), 153 M parameters, batch 25.
+# Two files: the front end at 299x299 (2 frames: digests + heads of all 18 end points, Mixed_7c of frame 0 whole) and the translator at
+# 8x8x2048, batch 25 (seeds, the four scalars, whole out / out2 maps of two triples, per-triple digests, and per gradient tensor a
+# digest, 16 random-sign projections and 1024 sampled entries -- the b256 scheme; two Adam steps' scalars).
+# Needs ~12 GB and a few minutes here:  python tests/golden/make_golden.py ref299
+# ------------------------------------------------------------------------------------------------------------------
+REF299_FRONT_TAG = "inception_v3_299x299_b2"
+REF299_TAG = "incep2_8x8x2048_f1024_b25"
+REF299_SEEDS = dict(pseed=3100, fseed=41, proj_seed=7, sample_seed=8)
+REF299_NPROJ, REF299_NSAMP, REF299_B = 16, 1024, 25
+REF299_KEEP = (24,)
+
+
+def ref299_case():
+    """(cfg, params float32-representable float64, [src, ctx, tgt] float32 post-ReLU maps) of the batch-25 fixture."""
+    from oracle import ctx_oracle_incep as ci
+    cfg = ci.Incep2Config(H=8, W=8)
+    p = ci.init_params(cfg, REF299_SEEDS["pseed"], np.float32, stddev=0.02)
+    brng = np.random.default_rng(REF299_SEEDS["pseed"] + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = (brng.standard_normal(p[n].shape) * 0.02).astype(np.float32)
+    frng = np.random.default_rng(REF299_SEEDS["fseed"])
+    feats = [np.maximum(frng.standard_normal((REF299_B, cfg.H, cfg.W, cfg.C)), 0.0).astype(np.float32) for _ in range(3)]
+    return cfg, p, feats
+
+
+def ref299_probes(name_sizes):
+    out = {}
+    for i, (n, size) in enumerate(name_sizes):
+        rs = np.random.default_rng(REF299_SEEDS["sample_seed"] * 1000 + i)
+        idx = np.sort(rs.choice(size, min(REF299_NSAMP, size), replace=False))
+        out[n] = (REF299_SEEDS["proj_seed"] * 1000 + i, idx)
+    return out
+
+
+def ref299_project(a, seed):
+    a = np.asarray(a, np.float64).reshape(-1)
+    rng = np.random.default_rng(seed)
+    return np.array([float(a @ (rng.integers(0, 2, a.size, dtype=np.int8) * 2.0 - 1.0)) for _ in range(REF299_NPROJ)])
+
+
+def make_ref299():
+    import time
+    from oracle import ctx_oracle_incep as ci
+    t0 = time.time()
+    make_inception_v3_299()
+    cfg, p32, feats = ref299_case()
+    B = REF299_B
+    p = {k: v.astype(np.float64) for k, v in p32.items()}
+    src, ctx, tgt = (x.astype(np.float64) for x in feats)
+    names = [n for n, _ in ci.param_specs(cfg)]
+    fx = dict(cfg=np.array([cfg.H, cfg.W, cfg.C, cfg.featsize]), strides=np.array(cfg.strides), kernels=np.array(cfg.kernels),
+              filters=np.array(cfg.filters), B=B, stddev=0.02, lr=1e-4, keep=np.array(REF299_KEEP),
+              **{k: np.array(v) for k, v in REF299_SEEDS.items()})
+    fx["param_digest"], _ = digest(ci.flatten(p, cfg))
+    res, c = ci.forward(p, src, ctx, tgt, cfg)
+    print(f"forward {time.time() - t0:.0f}s loss {res['loss']:.6g}", flush=True)
+    fx["scalars"] = np.array([res["loss"], res["simloss"], res["recon1"], res["recon2"]])
+    for k in ("out", "out2", "translated_z", "input_z"):
+        fx[k + "_keep"] = res[k][list(REF299_KEEP)].astype(np.float32)
+        flat = res[k].reshape(B, -1)
+        fx[k + "_rows"] = np.stack([flat.sum(1), np.abs(flat).sum(1), np.sqrt((flat * flat).sum(1))], 1)
+    g = ci.backward(p, c, cfg)
+    print(f"backward {time.time() - t0:.0f}s", flush=True)
+    probes = ref299_probes([(n, g[n].size) for n in names])
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_proj"] = np.stack([ref299_project(g[n], probes[n][0]) for n in names])
+    fx["grad_samples"] = np.stack([np.pad(g[n].reshape(-1)[probes[n][1]], (0, REF299_NSAMP - len(probes[n][1]))) for n in names])
+    # the reward hook's fetches at its batch (base.py:216-218, :234-235 with image_trans = feature maps)
+    pred, feat = ci.translate(p, src, ctx[0], cfg)
+    fx["translate_pred_keep"], fx["translate_feat"] = pred[list(REF299_KEEP)].astype(np.float32), feat.astype(np.float32)
+    fx["encode_feat"] = ci.encode(p, src, cfg).astype(np.float32)
+    # two Adam steps (train_script.py:163): scalars before each update
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    o.adam_step(p, g, m, v, 1, 1e-4)
+    del g, c
+    rr, cc = ci.forward(p, src, ctx, tgt, cfg)
+    fx["train_scalars"] = np.array([fx["scalars"], [rr["loss"], rr["simloss"], rr["recon1"], rr["recon2"]]])
+    path = os.path.join(HERE, f"{REF299_TAG}.npz")
+    np.savez_compressed(path, **fx)
+    print(REF299_TAG, os.path.getsize(path), "bytes; loss", fx["scalars"][0], "->", rr["loss"], f"{time.time() - t0:.0f}s")
+
+
+def make_inception_v3_299():
+    """Inception-v3 to Mixed_7c at the reference's own 299x299 (nets/inception_v3_test.py:45-54: Mixed_7c = [N, 8, 8, 2048]): two
+    seeded uint8 frames (regenerated by the tests), digest + head of every end point, Mixed_7c of frame 0 whole."""
+    from oracle import inception_oracle as io
+    p = {k: v.astype(np.float64) for k, v in io.init_params(0, np.float32).items()}      # float32-representable: what the device holds
+    frames = np.random.default_rng(REF299_SEEDS["fseed"] + 1).integers(0, 256, (2, 299, 299, 3), dtype=np.uint8)
+    ep = io.forward(p, o.preprocess_u8(frames).astype(np.float64))
+    fx = dict(pseed=0, fseed=REF299_SEEDS["fseed"] + 1, B=2, S=299, endpoints=np.array(list(ep)),
+              frames_digest=digest(frames)[0], Mixed_7c_0=ep["Mixed_7c"][0].astype(np.float32),
+              endpoint_shapes=np.stack([np.array(v.shape) for v in ep.values()]),
+              endpoint_digest=np.stack([digest(v)[0] for v in ep.values()]),
+              endpoint_head=np.stack([digest(v)[1] for v in ep.values()]))
+    fx["param_digest"], _ = digest(np.concatenate([np.asarray(v).reshape(-1) for v in p.values()]))
+    path = os.path.join(HERE, f"{REF299_FRONT_TAG}.npz")
+    np.savez_compressed(path, **fx)
+    print(REF299_FRONT_TAG, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ref299":
+    make_ref299()

@@ -20,7 +20,12 @@ class OracleEngine:
     """Same interface as dp.HipEngine (params / grads flat tensors, forward_backward, adam,
     scalars_tensor), arithmetic from the float64 oracle."""
 
-    def __init__(self, seed):
+    def __init__(self, seed, ablation="None"):
+        import types
+        self.ablation = ablation
+        # what dp.DataParallelTrainer reads the loss switch from: Translator.cfg.loss_terms (CTX_LOSS_* bits; 0 = all)
+        bits = {"None": 0, "L2": 3, "L2L3": 1, "L1": 6}[ablation]
+        self.translator = types.SimpleNamespace(cfg=types.SimpleNamespace(loss_terms=bits))
         self.p = o.init_params(CFG, seed, np.float64, stddev=0.2)
         self.n_params = o.param_count(CFG)
         self.params = torch.from_numpy(o.flatten(self.p, CFG).copy())
@@ -32,7 +37,7 @@ class OracleEngine:
 
     def forward_backward(self, src, ctx, tgt, sim_batch, bucket_cb=None):
         self.p = o.unflatten(self.params.numpy().copy(), CFG)
-        res, c = o.forward(self.p, src.numpy(), ctx.numpy(), tgt.numpy(), CFG)
+        res, c = o.forward(self.p, src.numpy(), ctx.numpy(), tgt.numpy(), CFG, ablation_type=self.ablation)
         g = o.backward(self.p, c, CFG, sim_batch=sim_batch)
         self.grads.copy_(torch.from_numpy(o.flatten(g, CFG)))
         if bucket_cb is not None:           # like the HIP engine: the tail of the arena (translate/*, deconv/*) is announced first
@@ -55,7 +60,7 @@ def _data(B):
     return [torch.from_numpy(rng.uniform(-1, 1, (B, 16, 16, 3))) for _ in range(3)]
 
 
-def _worker(rank, world, port, q, overlap="0"):
+def _worker(rank, world, port, q, overlap="0", ablation="None"):
     os.environ["CTX_DP_OVERLAP"] = overlap          # "1": two buckets, the tail announced from inside the backward pass
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -65,7 +70,7 @@ def _worker(rank, world, port, q, overlap="0"):
     src, ctx, tgt = _data(B)
     sh = slice(rank * B // world, (rank + 1) * B // world)
     # different seeds per rank: the constructor's broadcast must make replicas identical
-    tr = DataParallelTrainer(engine=OracleEngine(seed=7 + rank))
+    tr = DataParallelTrainer(engine=OracleEngine(seed=7 + rank, ablation=ablation))
     p0 = tr.engine.params.clone()
     tr.step(src[sh], ctx[sh], tgt[sh], lr=1e-3)
     g1 = tr.engine.grads.clone()
@@ -85,13 +90,15 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("overlap", ["0", "1"])
-def test_two_rank_data_parallel_equals_full_batch(overlap):
+@pytest.mark.parametrize("overlap,ablation", [("0", "None"), ("1", "None"), ("0", "L1"), ("0", "L2L3")])
+def test_two_rank_data_parallel_equals_full_batch(overlap, ablation):
+    """ablation != "None": the loss switch of ablations_code/ablations.py:175-182 -- the global `loss` is rebuilt from the reduced
+    terms it keeps (dp.py: _scalars), the gradients are those of that loss."""
     world = 2
     ctxm = mp.get_context("spawn")
     q = ctxm.Queue()
     port = _free_port()
-    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, overlap)) for r in range(world)]
+    procs = [ctxm.Process(target=_worker, args=(r, world, port, q, overlap, ablation)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
@@ -99,7 +106,7 @@ def test_two_rank_data_parallel_equals_full_batch(overlap):
         p.join(60)
         assert p.exitcode == 0
     # single-process full-batch reference with rank 0's initial parameters
-    ref = OracleEngine(seed=7)
+    ref = OracleEngine(seed=7, ablation=ablation)
     src, ctx, tgt = _data(4)
     np.testing.assert_array_equal(got[0][1], got[1][1])                 # broadcast made replicas equal
     np.testing.assert_array_equal(got[0][1], ref.params.numpy())

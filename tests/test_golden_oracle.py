@@ -89,3 +89,37 @@ def test_inception_oracle_reproduces_golden():
     assert list(ep) == [str(n) for n in z["endpoints"]]
     np.testing.assert_allclose(ep["Mixed_7c"], z["Mixed_7c"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(np.stack([digest(v) for v in ep.values()]), z["endpoint_digest"], rtol=1e-9)
+
+
+def test_inception_oracle_reproduces_the_299x299_golden():
+    """The front end at the reference's own frame size (nets/inception_v3_test.py:45-54): tests/golden/make_golden.py ref299."""
+    from oracle import inception_oracle as io
+    from tests.golden import make_golden as mg
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", mg.REF299_FRONT_TAG + ".npz"))
+    frames = np.random.default_rng(int(z["fseed"])).integers(0, 256, (2, 299, 299, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(digest(frames), z["frames_digest"])
+    p = {k: v.astype(np.float64) for k, v in io.init_params(int(z["pseed"]), np.float32).items()}
+    ep = io.forward(p, o.preprocess_u8(frames).astype(np.float64))
+    assert list(ep) == [str(n) for n in z["endpoints"]]
+    assert ep["Mixed_7c"].shape == (2, 8, 8, 2048)
+    np.testing.assert_allclose(ep["Mixed_7c"][0], z["Mixed_7c_0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.stack([digest(v) for v in ep.values()]), z["endpoint_digest"], rtol=1e-9)
+
+
+def test_incep2_oracle_reproduces_the_reference_size_golden():
+    """ContextAEInception2 at 8x8x2048, batch 25, 153 M parameters (run_train_strike_inception.py:39-43): parameters and inputs are
+    regenerated from the recorded seeds; forward outputs and scalars of the float64 oracle against the fixture (the gradient digests
+    are guarded by the generator run; a backward pass here would double the test's 10 GB)."""
+    from oracle import ctx_oracle_incep as ci
+    from tests.golden import make_golden as mg
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", mg.REF299_TAG + ".npz"))
+    cfg, p32, feats = mg.ref299_case()
+    np.testing.assert_allclose(digest(ci.flatten(p32, cfg)), z["param_digest"], rtol=1e-12)
+    assert ci.param_count(cfg) == 153_111_040
+    p = {k: v.astype(np.float64) for k, v in p32.items()}
+    del p32
+    res, _ = ci.forward(p, *(x.astype(np.float64) for x in feats), cfg)
+    np.testing.assert_allclose([res["loss"], res["simloss"], res["recon1"], res["recon2"]], z["scalars"], rtol=1e-12)
+    keep = list(z["keep"])
+    for k in ("out", "out2", "translated_z", "input_z"):
+        np.testing.assert_allclose(res[k][keep], z[k + "_keep"], rtol=1e-5, atol=1e-6)

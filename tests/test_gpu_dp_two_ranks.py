@@ -110,3 +110,21 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
     np.testing.assert_allclose(z[0]["cache_means"], z[0]["solo_means"], rtol=1e-6, atol=1e-7)
     np.testing.assert_allclose(z[0]["cache_imgs"], z[0]["solo_imgs"], rtol=1e-6, atol=1e-7)
     assert np.abs(z[0]["cache_means"]).max() > 0
+    # ---- the loss switch "L1" (recon2 + simloss) on two ranks: the global `loss` holds those terms only (ctx_dp_scalars
+    # used to rebuild simloss + recon1 + recon2 whatever the switch), and the reduced gradient is the oracle's for that loss
+    p0 = {k: v.astype(np.float64) for k, v in o.init_params(cfg, wk.PSEED, np.float32, stddev=0.05).items()}
+    ares, ac = o.forward(p0, src, ctx, tgt, cfg, ablation_type="L1")
+    awant = np.array([ares["loss"], ares["simloss"], ares["recon1"], ares["recon2"]])
+    assert abs(ares["loss"] - (ares["recon2"] + ares["simloss"])) <= 1e-12 * ares["loss"]
+    for key in ("abl_scalars", "abl_scalars_again"):
+        np.testing.assert_allclose(z[0][key], awant, rtol=2e-5)
+        np.testing.assert_array_equal(z[0][key], z[1][key])
+    assert abs(z[0]["abl_scalars"][0] - (z[0]["abl_scalars"][3] + z[0]["abl_scalars"][1])) <= 1e-6 * z[0]["abl_scalars"][0]
+    ag = o.flatten(o.backward(p0, ac, cfg), cfg)
+    np.testing.assert_array_equal(z[0]["abl_grads"], z[1]["abl_grads"])
+    off = 0
+    for name, shape in o.param_specs(cfg):
+        n = int(np.prod(shape))
+        a, b = z[0]["abl_grads"][off:off + n].astype(np.float64), ag[off:off + n]
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 1e-12, (name, np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+        off += n

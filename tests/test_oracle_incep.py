@@ -76,3 +76,25 @@ def test_finite_difference_spot_check():
         q[name][idx] -= 2 * eps
         lm = oi.forward(q, src, ctx, tgt, cfg)[0]["loss"]
         assert abs((lp - lm) / (2 * eps) - g[name][idx]) <= 1e-5 * max(1.0, abs(g[name][idx])), name
+
+
+@pytest.mark.parametrize("ablation", ["L2", "L2L3", "L1"])
+def test_oracle_loss_ablations_match_torch_autograd(ablation):
+    """The loss switch of ablations_code/ablations.py:175-182 on ContextAEInception2's graph: `loss` and every gradient for the
+    selected terms against torch autograd of that sum."""
+    from oracle.ctx_oracle import LOSS_ABLATIONS
+    H, W, C, filters, B = 4, 4, 8, (8, 8, 4, 4), 2
+    cfg = oi.Incep2Config(H=H, W=W, C=C, featsize=16, filters=filters)
+    p = oi.init_params(cfg, 5, np.float64, stddev=0.2)
+    rng = np.random.default_rng(6)
+    src, ctx, tgt = (rng.standard_normal((B, H, W, C)) for _ in range(3))
+    res, c = oi.forward(p, src, ctx, tgt, cfg, ablation_type=ablation)
+    g = oi.backward(p, c, cfg)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    tres = tr.forward_incep2(tp, *(torch.tensor(a) for a in (src, ctx, tgt)), H, W, cfg.strides, cfg.filters)
+    tloss = sum(tres[t] for t in LOSS_ABLATIONS[ablation])
+    np.testing.assert_allclose(res["loss"], tloss.item(), rtol=1e-10)
+    tloss.backward()
+    for n in g:
+        tg = tp[n].grad.numpy() if tp[n].grad is not None else np.zeros_like(p[n])
+        np.testing.assert_allclose(g[n], tg, rtol=1e-8, atol=1e-10, err_msg=n)

@@ -98,3 +98,26 @@ def test_oracle_reproduces_real_golden():
     g = r.backward(p, c, cfg)
     for i, (n, _) in enumerate(r.param_specs(cfg)):
         np.testing.assert_allclose(dg(g[n]), z["grad_digest"][i], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("ablation", ["L2", "L2L3", "L1"])
+def test_real_oracle_loss_ablations_match_torch_autograd(ablation):
+    """ablations_code/ablations.py:477-484 (ContextAESweep / ContextAEPushReal carry the same switch, :175-182): the oracle's
+    `loss` and every gradient for the selected terms against torch autograd of that sum."""
+    H, W, B = 12, 8, 3
+    cfg = r.RealConfig(H=H, W=W)
+    p = r.init_params(cfg, 13, np.float64, stddev=0.2)
+    rng = np.random.default_rng(14)
+    src, ctx, tgt = (rng.uniform(-1, 1, (B, H, W, 3)) for _ in range(3))
+    res, c = r.forward(p, src, ctx, tgt, cfg, ablation_type=ablation)
+    g = r.backward(p, c, cfg)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    tres = tr.forward_real(tp, *(torch.tensor(a, dtype=torch.float64) for a in (src, ctx, tgt)), H, W)
+    tloss = sum(tres[t] for t in o.LOSS_ABLATIONS[ablation])
+    assert abs(res["loss"] - tloss.item()) <= 1e-10 * abs(tloss.item())
+    for k in ("simloss", "recon1", "recon2"):                                   # reported whatever the switch
+        assert abs(res[k] - tres[k].item()) <= 1e-10 * abs(tres[k].item())
+    tloss.backward()
+    for k in g:
+        tg = tp[k].grad.numpy() if tp[k].grad is not None else np.zeros_like(p[k])
+        assert np.abs(g[k] - tg).max() <= 1e-9 * (np.abs(tg).max() + 1e-30) + 1e-30, k
