@@ -33,6 +33,37 @@ PEAK_HBM = 8.0e12
 PEAK_BF16_MFMA = 2.5e15                            # dense; a split product costs 3 bf16 MFMA flops per algorithmic flop
 
 
+def skipnew_flops_per_triple(H, W, d=DF, F=FEAT, useful=False):
+    """fwd+bwd FLOPs of one ContextSkipNew triple (2 per multiply-add; arm_shaping.py:1272-1354: 3 encoder images, translate MLP,
+    2 decoder passes; backward = input + filter gradient of every layer except the first convs' input gradient).
+    useful=False: SURVEY.md 8d's convention -- every one of the 25 taps counted at every position (7,072,382,976 at 64x64).
+    useful=True: only the (position, tap) pairs whose tap lies inside the image -- (5n-3)^2 of (5n)^2 on an n x n small grid -- i.e.
+    the products that do not multiply SAME padding; what a kernel that skips those has to execute."""
+    def frac(n):
+        return (5 * n - 3) / (5.0 * n) if useful else 1.0
+    h, w, cin = H, W, 3
+    enc, first, dec = 0.0, 0.0, 0.0
+    chans = [d, 2 * d, 4 * d, 8 * d]
+    grids = []
+    for k in range(4):
+        h, w = h // 2, w // 2
+        fl = 2.0 * h * w * 25 * cin * chans[k] * frac(h) * frac(w)
+        enc += fl
+        if k == 0:
+            first = fl
+        grids.append((h, w))
+        cin = chans[k]
+    d0 = grids[3][0] * grids[3][1] * 8 * d
+    fc = 3 * 2.0 * (d0 * F + F * F) + 2.0 * (2 * F * F + F * F) + 2 * 2.0 * F * d0
+    for k in range(1, 5):                                    # d_hk: input grid = encoder layer 4-k's output grid, channels [decoder | skip]
+        hi, wi = grids[4 - k]
+        c_in = 2 * chans[4 - k]
+        c_out = chans[3 - k] if k < 4 else 3
+        dec += 2.0 * hi * wi * 25 * c_in * c_out * frac(hi) * frac(wi)
+    fwd = 3 * enc + fc + 2 * dec
+    return 3.0 * fwd - 3 * first
+
+
 def csrc_sha16():
     """Identity of the kernel sources this tree builds libctxtrans.so from: the PMC-derived traffic figures under profiles/
     carry the hash of the sources they were measured on (tools/hbm_aggregate.py) and are only quoted for the same sources."""
@@ -344,6 +375,9 @@ def main():
                     help="skip the extra bf16x3 measurement that a default (f32) run appends as line['bf16x3']")
     ap.add_argument("--sustained-s", type=float, default=3.0,
                     help="after the timed run, keep stepping for at least this many seconds and report sustained_ms_per_step (0 = skip)")
+    ap.add_argument("--no-sampled", action="store_true",
+                    help="skip the extra leg that runs the trainer's own step (ctx_train_step_sampled / ctx_dp_train_step_sampled: the batch "
+                         "gathered on the device from a resident uint8 demo tensor, global index arrays from the host) -- line['sampled']")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary legs (ContextAEReal 36x64 B=256, config-4 share) a default 1-GPU run appends as line['secondary']")
     args = ap.parse_args()
@@ -400,7 +434,10 @@ def main():
         flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            dp_client = "torch"
+            # no silent change of client: the number would be another schedule's (one all-reduce after backward, no overlap).  Ask for
+            # it by name (BENCH_DP=torch) if that is what should be measured.
+            raise SystemExit(f"bench.py: rank {rank}: the C-ABI RCCL client (ctx_dp_*) is unavailable on at least one rank; "
+                             "set BENCH_DP=torch to measure the torch.distributed client instead")
     if dp_client == "cabi":
         trainer = RcclTrainer(H, W, DF, FEAT, max_batch=B, device=local_rank, seed=1234, rank=rank, world=world, precision=args.precision)
     else:
@@ -461,6 +498,45 @@ def main():
             dts = float(tmax.item())
         sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": 1e3 * dts / n_sus, "frames_per_s": n_sus * B * world / dts}
 
+    # The trainer's own step (never `value`): a uint8 demo tensor [25 frames, 64 videos] resident in HBM, per step the host hands over
+    # the two GLOBAL index arrays (np.random.choice, train_script.py:154-155) and every rank gathers its rows on the device.  Includes the
+    # host-side enqueue of each step and the 2 x 4 B x world bytes of indices.
+    sampled = None
+    if not args.no_sampled and dp_client in ("cabi", "single") and args.precision == "f32":
+        try:
+            trl = trainer.translator
+            rng = np.random.default_rng(5)
+            trl.load_demos(rng.integers(0, 256, (25, 64, H, W, 3), dtype=np.uint8))
+            Bg = B * world
+            draws = [(rng.integers(0, 64, Bg), rng.integers(0, 64, Bg)) for _ in range(8)]
+
+            def sstep(i):
+                cs, ct = draws[i % len(draws)]
+                if dp_client == "cabi":
+                    trl.dp_train_step_sampled(cs, ct, lr=1e-4, scalars=False)
+                else:
+                    trl.train_step_sampled(cs, ct, lr=1e-4)          # (synchronous: returns the four scalars, as the reference's sess.run does)
+
+            for i in range(args.warmup):
+                sstep(i)
+            trl.sync()
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                sstep(i)
+            trl.sync()
+            barrier()
+            dts = time.perf_counter() - t0
+            if world > 1:
+                tmax = torch.tensor([dts], device="cuda", dtype=torch.float64)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dts = float(tmax.item())
+            sampled = {"ms_per_step": 1e3 * dts / args.steps, "frames_per_s": args.steps * Bg / dts, "steps": args.steps,
+                       "demo_tensor": "uint8 [25, 64, 64, 64, 3] resident per rank", "global_batch": Bg,
+                       "entry": "ctx_dp_train_step_sampled" if dp_client == "cabi" else "ctx_train_step_sampled (synchronous, scalars fetched every step)"}
+        except Exception as e:                      # an extra leg must never cost the bench line
+            sampled = {"error": repr(e)[:300]}
+
     ms = 1e3 * dt / args.steps
     value = args.steps * B * world / dt
     line = {
@@ -478,10 +554,17 @@ def main():
                                  "single": "none (one rank)"}[dp_client]},
         "loss_after": scal["loss"],
         "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
+        "sampled": sampled,
         "step_ms_hip_events": step_events,          # rank 0's stream; `ms_per_step` / `value` are the wall-clock mean, max over ranks
         "step_rates": {
             "tflops_f32": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / 1e12,
             "frac_f32_mfma_peak": FLOPS_FWD_BWD_PER_TRIPLE * B / (dt / args.steps) / PEAK_F32_MFMA,
+            # the same step priced on USEFUL flops: products with SAME-padding zeros left out (15.5 % of SURVEY 8d's count at 64x64) --
+            # the figure a kernel cannot inflate by multiplying zeros, nor "exceed the peak" with by skipping them
+            "flops_per_triple_all_taps": FLOPS_FWD_BWD_PER_TRIPLE,
+            "flops_per_triple_useful": skipnew_flops_per_triple(H, W, useful=True),
+            "tflops_useful": skipnew_flops_per_triple(H, W, useful=True) * B / (dt / args.steps) / 1e12,
+            "useful_frac_f32_mfma_peak": skipnew_flops_per_triple(H, W, useful=True) * B / (dt / args.steps) / PEAK_F32_MFMA,
             "algorithmic_hbm_GBps": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / 1e9,
             "frac_hbm_peak": (BYTES_PER_TRIPLE * B + BYTES_PER_STEP_FIXED) / (dt / args.steps) / PEAK_HBM,
             # where the step sits on the roofline: its arithmetic intensity is far right of the ridge (peak flops / HBM
@@ -550,11 +633,17 @@ def main():
         kname, k = next(iter(tab.items()))          # the kernel with the most time in a step
         per_launch_ms = k["ms"] / k["launches"]
         ach = k["flops"] / (k["ms"] * 1e-3)
+        ach_useful = k["useful_flops"] / (k["ms"] * 1e-3)
         # f32: algorithmic flops against the f32-MFMA peak.  bf16x3: every algorithmic flop is 3 bf16 MFMA flops, so the
         # algorithmic rate is priced against (dense bf16 peak) / 3.
         peak = PEAK_F32_MFMA if args.precision == "f32" else PEAK_BF16_MFMA / 3
         line["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach / 1e12, "peak": peak / 1e12,
-                            "unit": "TFLOP/s", "frac": ach / peak, "launches_per_step": k["launches"],
+                            "unit": "TFLOP/s", "frac": ach / peak,
+                            # `achieved` / `frac` count all 25 taps at every position; `*_useful` leave out the products
+                            # with SAME-padding zeros (valid (position, tap) pairs only): the honest utilisation of the matrix pipe
+                            "achieved_useful": ach_useful / 1e12, "useful_frac": ach_useful / peak,
+                            "useful_share_of_flops": k["useful_flops"] / k["flops"] if k["flops"] else None,
+                            "launches_per_step": k["launches"],
                             "avg_ms_per_launch": per_launch_ms, "flops_per_launch": k["flops"] / k["launches"],
                             "share_of_step_ms": k["ms"] / sum(t["ms"] for t in tab.values()), "traffic": None}
         # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
@@ -581,13 +670,19 @@ def main():
             else:
                 line["roofline"]["traffic_stale_source"] = os.path.basename(prof[-1])
         line["kernels"] = {n: {"ms": round(t["ms"], 4), "launches": t["launches"],
-                               "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None}
+                               "tflops": round(t["flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None,
+                               "tflops_useful": round(t["useful_flops"] / (t["ms"] * 1e-3) / 1e12, 2) if t["flops"] else None}
                            for n, t in tab.items()}
+        # serialised launch groups of one step: all-taps and useful flops as the library counts them (cross-check of the closed forms)
+        line["step_rates"]["profiled_gflop_per_step"] = sum(e["flops"] for e in ents) / 1e9
+        line["step_rates"]["profiled_useful_gflop_per_step"] = sum(e["useful_flops"] for e in ents) / 1e9
+        line["step_rates"]["profiled_serialised_ms"] = sum(e["ms"] for e in ents)
         if os.environ.get("BENCH_LAYER_TABLE"):
             with open(os.environ["BENCH_LAYER_TABLE"], "w") as f:
                 for e in ents:
                     tf = e["flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else 0
-                    f.write(f"{e['name']:34s} {e['kernel']:34s} {e['ms']:9.4f} ms {tf:8.2f} TF/s\n")
+                    tu = e["useful_flops"] / (e["ms"] * 1e-3) / 1e12 if e["ms"] > 0 else 0
+                    f.write(f"{e['name']:34s} {e['kernel']:34s} {e['ms']:9.4f} ms {tf:8.2f} TF/s all taps {tu:8.2f} TF/s useful ({tu / (peak / 1e12):5.3f} of peak)\n")
         if args.host_buffers:
             hs, hc, ht = (x.cpu().numpy() for x in (src, ctx, tgt))
             tr.train_step(hs, hc, ht, lr=1e-4)

@@ -29,7 +29,7 @@ LOSS_ABLATIONS = {"None": 7, "L2": 3, "L2L3": 1, "L1": 6}
 
 class CtxProfEntry(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 56), ("kernel", ctypes.c_char * 40), ("flops", ctypes.c_double),
-                ("ms", ctypes.c_float), ("reserved", ctypes.c_float)]
+                ("ms", ctypes.c_float), ("useful_frac", ctypes.c_float)]
 
 
 class CtxError(RuntimeError):
@@ -111,6 +111,8 @@ SIGNATURES = {
     "ctx_dp_allreduce_grads": (_c.c_int, [_P]),
     "ctx_dp_train_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _F]),
     "ctx_dp_scalars": (_c.c_int, [_P, _F]),
+    "ctx_dp_train_step_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _c.c_float, _F]),
+    "ctx_dp_eval_sampled": (_c.c_int, [_P, _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32), _c.c_int, _F, _F, _F]),
     "ctx_dp_allreduce_host_f64": (_c.c_int, [_P, _c.POINTER(_c.c_double), _c.c_size_t]),
     "ctx_profile_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float, _c.c_int, _c.POINTER(CtxProfEntry), _c.c_int,
                                     _c.POINTER(_c.c_int)]),

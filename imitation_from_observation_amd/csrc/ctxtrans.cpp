@@ -169,7 +169,8 @@ int fail(ctx_handle* h, int code, const char* fmt, ...) {
 struct ProfScope {
     ctx_handle* h;
     int idx = -1;
-    ProfScope(ctx_handle* h_, const std::string& name, const char* kernel, double flops) : h(h_) {
+    // useful: share of `flops` whose product meets two data operands (tap_frac for SAME-padded convolutions; 1 elsewhere)
+    ProfScope(ctx_handle* h_, const std::string& name, const char* kernel, double flops, double useful = 1.0) : h(h_) {
         if (!h->prof_on) return;
         idx = h->prof_cursor++;
         if ((int)h->prof_entries.size() <= idx) {
@@ -177,6 +178,7 @@ struct ProfScope {
             snprintf(e.name, sizeof e.name, "%s", name.c_str());
             snprintf(e.kernel, sizeof e.kernel, "%s", kernel);
             e.flops = flops;
+            e.useful_frac = (float)useful;
             h->prof_entries.push_back(e);
             h->prof_ms.push_back(0.0);
             hipEvent_t a, b;
@@ -191,6 +193,34 @@ struct ProfScope {
         if (idx >= 0) (void)hipEventRecord(h->prof_ev[2 * idx + 1], h->stream);
     }
 };
+
+// Share of a SAME-padded K x K stride-s layer's (position, tap) pairs whose tap lies INSIDE the image: the products of the conv, of
+// its transposed conv and of its filter gradient that multiply data and not padding zeros.  n_big = the layer's large grid (conv
+// input = transposed-conv output); TF's rule: out = ceil(n / s), pad_total = max((out - 1) s + K - n, 0), before = total / 2.
+// 5x5 stride 2 on an even grid: (5 n_small - 3) / (5 n_small) per axis -- 92.6 / 85.6 / 72.3 % in 2-D on 16x16 / 8x8 / 4x4 grids.
+double tap_frac1(int n_big, int K, int s) {
+    const int n_small = (n_big + s - 1) / s;
+    const int total = std::max((n_small - 1) * s + K - n_big, 0), before = total / 2;
+    int64_t valid = 0;
+    for (int i = 0; i < n_small; ++i)
+        for (int k = 0; k < K; ++k) {
+            const int y = s * i + k - before;
+            valid += y >= 0 && y < n_big;
+        }
+    return (double)valid / ((double)K * n_small);
+}
+double tap_frac(int hb, int wb, int K, int s) { return tap_frac1(hb, K, s) * tap_frac1(wb, K, s); }
+// the same count for a layer given by its own (stride, pad_before) -- the table-driven models' parameterisation
+double tap_frac_p1(int n_big, int n_small, int K, int s, int pad) {
+    int64_t valid = 0;
+    for (int i = 0; i < n_small; ++i)
+        for (int k = 0; k < K; ++k) {
+            const int y = s * i + k - pad;
+            valid += y >= 0 && y < n_big;
+        }
+    return (double)valid / ((double)K * n_small);
+}
+double tap_frac_p(int hb, int wb, int hs, int ws, int K, int s, int pad) { return tap_frac_p1(hb, hs, K, s, pad) * tap_frac_p1(wb, ws, K, s, pad); }
 
 #define HIP_TRY(h, expr)                                                                          \
     do {                                                                                          \
@@ -575,7 +605,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     Epi ep;
     ep.out1 = y; ep.ld1 = cb; ep.bias = b; ep.lrelu = 1;
     const bool c3 = ca == 3 && use_dc3(h) && c3conv_ok(hb, wb, 2, cb, ep);
-    ProfScope ps(h, name + " fwd", ca == 3 ? (c3 ? K_C3CONV : use_dc3(h) ? K_DCFWD : K_C3FWD) : K_CONV, 2.0 * R * 25 * ca * cb);
+    ProfScope ps(h, name + " fwd", ca == 3 ? (c3 ? K_C3CONV : use_dc3(h) ? K_DCFWD : K_C3FWD) : K_CONV, 2.0 * R * 25 * ca * cb, tap_frac(hb, wb, 5, 2));
     if (c3) c3conv(h->stream, x, nimg, hb, wb, 2, w, cb, ep);
     else if (ca == 3 && use_dc3(h)) {
         DcFwd P{};
@@ -703,11 +733,11 @@ void forward(ctx_handle* h, int B, Mode mode) {
         const float* w = h->Wp((nm_ + "/w").c_str());
         const float* b = h->Wp((nm_ + "/biases").c_str());
         const float* skip = h->c[4 - k];
-        const double fl = 2.0 * nd * hs * ws * 25 * (c1 + c2) * ca;
+        const double fl = 2.0 * nd * hs * ws * 25 * (c1 + c2) * ca, uf = tap_frac(2 * hs, 2 * ws, 5, 2);
         if (k < 4) {
             const int R = nd * hs * ws;
             const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, ws, c1, c2, ca);
-            ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl);
+            ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl, uf);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
             if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, B, nd, hs, ws, w, ca, ep, ws_of(h));
@@ -719,10 +749,10 @@ void forward(ctx_handle* h, int B, Mode mode) {
         } else {
             const int R = nd * hs * ws;
             if (d_h4_direct(h, c1, c2, hs, ws, 2)) {
-                ProfScope ps(h, nm_ + " fwd", K_CONVT3D, fl);
+                ProfScope ps(h, nm_ + " fwd", K_CONVT3D, fl, uf);
                 convt3_direct(h->stream, dec, c1, skip, c2, B, nd, hs, ws, 2, w, b, h->out);
             } else {
-                { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl);
+                { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl, uf);
                   convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
                 { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
                   convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
@@ -757,7 +787,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
         const float* w = h->Wp((nm_ + "/w").c_str());
         const float* dec_in = k > 1 ? h->e[k - 1] : h->dz;      // decoder half of the concat input
         float* d_dec = k > 1 ? h->dE[k - 1] : h->dDz;
-        const double fl = 2.0 * R * 25 * cb * ca;
+        const double fl = 2.0 * R * 25 * cb * ca, uf = tap_frac(hb, wb, 5, 2);
         NmWgradSmall2 small{dec_in, c1, c1, h->c[4 - k], c2, B, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
         Epi eg;
         eg.out1 = h->Gp((nm_ + "/w").c_str()); eg.ld1 = cb;
@@ -772,25 +802,25 @@ void backward(ctx_handle* h, int B, int sim_batch) {
               DcWgrad Wg{};
               Wg.big = dy; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dec_in; Wg.ld1 = c1; Wg.c1 = c1; Wg.s2 = h->c[4 - k]; Wg.ld2 = c2; Wg.nmod2 = B; Wg.CB = cb;
               Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = 2 * B; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
-              ProfScope ps(h, nm_ + " dw", dw_label(Wg), fl);
+              ProfScope ps(h, nm_ + " dw", dw_label(Wg), fl, uf);
               dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats); }
             if (c3conv_ok(hb, wb, 2, cb, ed)) {
-                ProfScope ps(h, nm_ + " dx", K_C3CONV, fl);
+                ProfScope ps(h, nm_ + " dx", K_C3CONV, fl, uf);
                 c3conv(h->stream, dy, 2 * B, hb, wb, 2, w, cb, ed);
             } else {
-              ProfScope ps(h, nm_ + " dx", K_DCFWD, fl);
+              ProfScope ps(h, nm_ + " dx", K_DCFWD, fl, uf);
               DcFwd D{};
               D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack;
               dconv_conv(h->stream, D, 2, 1); }
         } else if (ca == 3) {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
-              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl); conv3_wgrad2(h->stream, NmC3WgradBig{c4of(h, dy), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
-            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl); conv3_fwd(h->stream, KmC3Gather{c4of(h, dy), hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
+              ProfScope ps(h, nm_ + " dw", K_C3WGRAD, fl, uf); conv3_wgrad2(h->stream, NmC3WgradBig{c4of(h, dy), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h)); }
+            { ProfScope ps(h, nm_ + " dx", K_C3FWD, fl, uf); conv3_fwd(h->stream, KmC3Gather{c4of(h, dy), hb, wb, hs, wsm, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ed, R, cb, ws_of(h)); }
         } else {
             { Side sd(h, LANE_DW);
               bias_grad(h, nm_, dy, (int64_t)2 * B * hb * wb, ca, h->Gp((nm_ + "/biases").c_str()));
-              ProfScope ps(h, nm_ + " dw", K_WGRAD, fl);
+              ProfScope ps(h, nm_ + " dw", K_WGRAD, fl, uf);
               if (rect_ok(2 * B) && rect_ok(B)) {
                   const RectGeo rg = make_rect(2 * B, hs, wsm, hb, wb, 2, 1, 5);
                   conv_wgrad2_r(h->stream, NmWgradBigR{dy, ca, ca, rg, g_zeros}, NmWgradSmall2R{dec_in, c1, c1, h->c[4 - k], c2, B, cb, rg, g_zeros}, eg, ca, cb, ws_of(h));
@@ -798,7 +828,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                   const PatchGeo pg = make_patch(2 * B, hs, wsm);
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
-            { ProfScope ps(h, nm_ + " dx", K_CONV, fl);
+            { ProfScope ps(h, nm_ + " dx", K_CONV, fl, uf);
               if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
               else conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
         }
@@ -852,7 +882,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             const int R = nimg * hs * wsm;
             const float* xin = k ? act[k - 1] : x;
             const std::string ln = scn + "/h" + std::to_string(k) + "_conv";
-            const double fl = 2.0 * R * 25 * ca * cb;
+            const double fl = 2.0 * R * 25 * ca * cb, uf = tap_frac(hb, wb, 5, 2);
             NmWgradSmall small{dA[k], cb, cb, nullptr, 0, 1, cb, hs * wsm, make_pixdiv(1, hs * wsm).ws_sh, R, g_zeros};
             Epi eg;
             eg.out1 = sc.gw[k]; eg.ld1 = cb;
@@ -864,17 +894,17 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                     Wg.big = xin; Wg.ldb = 3; Wg.CA = 3; Wg.s1 = dA[k]; Wg.ld1 = cb; Wg.c1 = cb; Wg.CB = cb;
                     Wg.hb = hb; Wg.wb = wb; Wg.hs = hs; Wg.ws = wsm; Wg.nimg = nimg; Wg.S = 2; Wg.pad = 1; Wg.out = eg.out1;
                     Wg.db = sc.gb[k];
-                    ProfScope ps(h, ln + " dw", dw_label(Wg), fl);
+                    ProfScope ps(h, ln + " dw", dw_label(Wg), fl, uf);
                     dconv_wgrad(h->stream, Wg, h->slab, h->slab_floats);
                 } else {
-                    ProfScope ps(h, ln + " dw", K_C3WGRAD, fl);
+                    ProfScope ps(h, ln + " dw", K_C3WGRAD, fl, uf);
                     conv3_wgrad(h->stream, NmC3WgradBig{c4of(h, xin), hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, cb, ws_of(h));
                 }
                 break;   // no gradient w.r.t. the frame
             }
             { Side sd(h, dw_lane);
               bias_grad(h, ln, dA[k], R, cb, sc.gb[k]);
-              ProfScope ps(h, ln + " dw", K_WGRAD, fl);
+              ProfScope ps(h, ln + " dw", K_WGRAD, fl, uf);
               if (rect_ok(nimg)) {
                   const RectGeo rg = make_rect(nimg, hs, wsm, hb, wb, 2, 1, 5);
                   conv_wgrad_r(h->stream, NmWgradBigR{xin, ca, ca, rg, g_zeros}, NmWgradSmallR{dA[k], cb, cb, rg, g_zeros}, eg, ca, cb, ws_of(h));
@@ -891,7 +921,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             }
             // (split-bf16 mode: the exact-f32 kernel only where it is the faster one -- the 16x16 grids' few-channel input gradients)
             const bool wide = (h->cfg.precision == CTX_PREC_F32 || hs == 16) && wconvt_ok(hs, wsm, cb, 0, ca);
-            ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl);
+            ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl, uf);
             if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed, ws_of(h));
             else if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
                                          KmConvTWeightsQ{sc.w[k], ca, cb, 5, g_zeros}, ed, ca, ws_of(h));
@@ -1705,15 +1735,9 @@ int ctx_dp_allreduce_grads(ctx_handle* h) {
     return CTX_OK;
 }
 
-int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr, float scalars[4]) {
-    TRY(check_B(h, B));
-    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
-    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
-    HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)B * h->npi * sizeof(float);
-    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+// the data-parallel step on the shard already in h->img = [tgt | src | ctx] (B triples): forward, backward with the simloss mean over the
+// GLOBAL batch, the gradient buckets sent from inside backward, the rest after it, Adam
+static int dp_step_on_img(ctx_handle* h, int B, float lr, float scalars[4]) {
     h->drop_on = true;
     forward(h, B, MODE_TRAIN);
     // two buckets: [split, Ppad) = translate/* + deconv/* leaves from inside backward (fire_bucket) and travels while the
@@ -1736,7 +1760,62 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     TRY(dp_wait(h));
     TRY(adam_step(h, lr));
     h->last_B = B;
+    { char msg[256]; if (take_launch_error(msg, sizeof msg)) return fail(h, CTX_E_DEVICE, "%s", msg); }
     HIP_TRY(h, hipGetLastError());
+    if (scalars) return ctx_dp_scalars(h, scalars);
+    return CTX_OK;
+}
+
+int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr, float scalars[4]) {
+    TRY(check_B(h, B));
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return dp_step_on_img(h, B, lr, scalars);
+}
+
+// This rank's shard of the trainer's batch, gathered on the device from the resident demo tensor: every rank is handed the SAME global
+// index arrays (train_script.py:154-155) and takes rows [rank * B/world, (rank + 1) * B/world) with t = b % T on the GLOBAL row b.
+static int dp_gather_shard(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B_global, int* B_local) {
+    if (!h) return CTX_E_INVALID;
+    if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
+    if (!h->vdata) return fail(h, CTX_E_STATE, "ctx_demos_upload first");
+    if (!choicesrc || !choicetgt) return fail(h, CTX_E_INVALID, "NULL index array");
+    if (B_global <= 0 || B_global % h->dp_world) return fail(h, CTX_E_INVALID, "global batch %d is not a multiple of the %d ranks", B_global, h->dp_world);
+    const int B = B_global / h->dp_world, b0 = h->dp_rank * B;
+    TRY(check_B(h, B));
+    for (int b = 0; b < B_global; ++b)      // (the whole array: every rank refuses the same bad call, so no rank is left waiting in a collective)
+        if (choicesrc[b] < 0 || choicesrc[b] >= h->vN || choicetgt[b] < 0 || choicetgt[b] >= h->vN)
+            return fail(h, CTX_E_INVALID, "video index out of range [0,%d)", h->vN);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc + b0, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt + b0, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, b0, h->lut, h->img);
+    *B_local = B;
+    return CTX_OK;
+}
+
+int ctx_dp_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B_global, float lr, float scalars[4]) {
+    int B = 0;
+    TRY(dp_gather_shard(h, choicesrc, choicetgt, B_global, &B));
+    return dp_step_on_img(h, B, lr, scalars);
+}
+
+int ctx_dp_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B_global, float scalars[4], float* out,
+                        float* out2) {
+    int B = 0;
+    TRY(dp_gather_shard(h, choicesrc, choicetgt, B_global, &B));
+    forward(h, B, MODE_TRAIN);
+    losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
+    h->last_B = B;
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    if (out) TRY(copy_d2h(h, out, h->out, bytes));
+    if (out2) TRY(copy_d2h(h, out2, h->out + B * h->npi, bytes));
+    TRY(finish(h));
     if (scalars) return ctx_dp_scalars(h, scalars);
     return CTX_OK;
 }
@@ -1813,7 +1892,7 @@ int ctx_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
+    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, 0, h->lut, h->img);
     TRY(fused_step(h, B, lr));
     h->last_B = B;
     if (scalars) HIP_TRY(h, hipMemcpyAsync(scalars, h->scalars, 4 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1830,7 +1909,7 @@ int ctx_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* cho
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipMemcpyAsync(h->choice, choicesrc, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->choice + h->Bm, choicetgt, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, h->lut, h->img);
+    gather_triples(h->stream, h->vdata, h->vT, h->vN, h->npi, h->choice, h->choice + h->Bm, B, 0, h->lut, h->img);
     forward(h, B, MODE_TRAIN);
     losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
     h->last_B = B;
@@ -1853,7 +1932,8 @@ int ctx_last_outputs(ctx_handle* h, float* out, float* out2, float* tgt) {
 }
 
 // Test hook: copy an internal device buffer to the host (names: img Z dZ cz th0 dz out dout dDz dsim2
-// dth0 dcz, s0..s4 c0..c4 dS0..dS4 dC0..dC4 dSk0..dSk3, e1..e3 dE1..dE3).  n = floats to copy.
+// dth0 dcz, s0..s4 c0..c4 dS0..dS4 dC0..dC4 dSk0..dSk3, e1..e3 dE1..dE3; ContextAEReal / ContextAEInception2: img Z dZ out dz th0
+// a0..a4 e1..e3).  n = floats to copy.
 int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n) {
     if (!h || !name || !host) return CTX_E_INVALID;
     const std::string s(name);
@@ -1864,6 +1944,17 @@ int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n) {
         return -1;
     };
     int k;
+    if (h->gen) {   // table-driven models: a0..a3 conv outputs over the stacked [tgt | src | ctx] images, a4 = h4 [3B, Fp], e1..e3, dz, th0, Z
+        const GenState& r = *h->gen;
+        if (s == "img") p = h->img; else if (s == "Z") p = h->Z; else if (s == "dZ") p = h->dZ; else if (s == "out") p = h->out;
+        else if (s == "dz") p = r.dz; else if (s == "th0") p = r.th0;
+        else if ((k = idx("a", 0, 4)) >= 0) p = r.a[k];
+        else if ((k = idx("e", 1, 3)) >= 0) p = r.e[k];
+        if (!p) return fail(h, CTX_E_INVALID, "unknown debug buffer '%s' (table-driven models: img Z dZ out dz th0 a0..a4 e1..e3)", name);
+        HIP_TRY(h, hipSetDevice(h->device));
+        HIP_TRY(h, hipMemcpyAsync(host, p, n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        return finish(h);
+    }
     if (s == "img") p = h->img; else if (s == "Z") p = h->Z; else if (s == "dZ") p = h->dZ;
     else if (s == "cz") p = h->cz; else if (s == "th0") p = h->th0; else if (s == "dz") p = h->dz;
     else if (s == "out") p = h->out; else if (s == "dout") p = h->dout; else if (s == "dDz") p = h->dDz;

@@ -330,7 +330,7 @@ void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int6
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS) void gather_triples_kernel(const uint8_t* __restrict__ vdata, int T, int N, int64_t npi,
                                                                   const int* __restrict__ csrc, const int* __restrict__ ctgt,
-                                                                  int B, const float* __restrict__ lut, float* __restrict__ img) {
+                                                                  int B, int b0, const float* __restrict__ lut, float* __restrict__ img) {
     __shared__ float sl[256];
     sl[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
@@ -339,17 +339,17 @@ __global__ __launch_bounds__(NTHREADS) void gather_triples_kernel(const uint8_t*
         const int64_t e4 = idx % per;
         const int64_t r = idx / per;
         const int b = (int)(r % B), slot = (int)(r / B);          // slot 0 tgt, 1 src, 2 ctx
-        const int t = slot == 2 ? 0 : b % T;
+        const int t = slot == 2 ? 0 : (b0 + b) % T;      // b0: this shard's first row of the GLOBAL batch (data parallel; else 0)
         const int v = slot == 1 ? csrc[b] : ctgt[b];
         const uchar4 u = *reinterpret_cast<const uchar4*>(vdata + ((int64_t)t * N + v) * npi + e4 * 4);
         *reinterpret_cast<float4*>(img + r * npi + e4 * 4) = make_float4(sl[u.x], sl[u.y], sl[u.z], sl[u.w]);
     }
 }
 
-void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B,
+void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B, int b0,
                     const float* lut, float* img) {
     hipLaunchKernelGGL(gather_triples_kernel, dim3(ew_blocks(3 * (int64_t)B * npi / 4)), dim3(NTHREADS), 0, s, vdata, T, N, npi,
-                       csrc, ctgt, B, lut, img);
+                       csrc, ctgt, B, b0, lut, img);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -118,7 +118,7 @@ void avgpool3x3s1(hipStream_t s, const float* in, float* out, int nimg, int hi, 
 void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows);
 
 // device batch sampler (scripts/train_script.py:153-159); lut[256] = f32(x / 127.5 - 1)
-void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B,
+void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B, int b0,
                     const float* lut, float* img);
 
 // Losses (arm_shaping.py:1345,1352-1354) and their seeds of the backward pass.

@@ -472,6 +472,41 @@ class Translator:
         if scalars:
             return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
 
+    def dp_train_step_sampled(self, choicesrc, choicetgt, lr=1e-4, scalars=True):
+        """The trainer's step on N GPUs (ctx_dp_train_step_sampled): every rank passes the SAME global index arrays
+        (np.random.choice(ntrain, batch_size) twice, train_script.py:154-155) and gathers its own rows of the batch from its resident
+        demo tensor (load_demos).  Returns the GLOBAL dict(loss, simloss, recon1, recon2) when scalars."""
+        cs = np.ascontiguousarray(choicesrc, dtype=np.int32)
+        ct = np.ascontiguousarray(choicetgt, dtype=np.int32)
+        if cs.shape != ct.shape or cs.ndim != 1:
+            raise ValueError("choicesrc / choicetgt must be 1-D and equally long")
+        sc = np.empty(4, np.float32) if scalars else None
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._ck(self._lib.ctx_dp_train_step_sampled(self._h, cs.ctypes.data_as(ip), ct.ctypes.data_as(ip), cs.size, float(lr),
+                                                     _fp(sc) if scalars else None))
+        if scalars:
+            return dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+
+    def dp_eval_sampled(self, choicesrc, choicetgt, outputs=True):
+        """The validation fetch sharded over the ranks (ctx_dp_eval_sampled; collective): GLOBAL scalars, and -- outputs=True -- out /
+        out2 of THIS rank's rows [B_global / world, H, W, 3]."""
+        cs = np.ascontiguousarray(choicesrc, dtype=np.int32)
+        ct = np.ascontiguousarray(choicetgt, dtype=np.int32)
+        if cs.shape != ct.shape or cs.ndim != 1:
+            raise ValueError("choicesrc / choicetgt must be 1-D and equally long")
+        world = max(1, self.dp_world()[1])
+        Bl = cs.size // world
+        sc = np.empty(4, np.float32)
+        out = np.empty((Bl, self.H, self.W, self.C), np.float32) if outputs else None
+        out2 = np.empty((Bl, self.H, self.W, self.C), np.float32) if outputs else None
+        ip = ctypes.POINTER(ctypes.c_int32)
+        self._ck(self._lib.ctx_dp_eval_sampled(self._h, cs.ctypes.data_as(ip), ct.ctypes.data_as(ip), cs.size, _fp(sc),
+                                               _fp(out) if outputs else None, _fp(out2) if outputs else None))
+        res = dict(loss=float(sc[0]), simloss=float(sc[1]), recon1=float(sc[2]), recon2=float(sc[3]))
+        if outputs:
+            res["out"], res["out2"] = out, out2
+        return res
+
     def dp_world(self):
         """(rank, world) of this handle's RCCL group; (0, 0) before dp_init (ctx_dp_world reports world 0 until a group exists)."""
         r, w = ctypes.c_int(0), ctypes.c_int(1)
@@ -504,21 +539,24 @@ class Translator:
 
     def profile_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4, iters=5):
         """Per-launch-group timing of a full train step (HIP events on the handle's stream).
-        Returns [dict(name, kernel, flops, ms)]."""
+        Returns [dict(name, kernel, flops, ms, useful_flops)]: flops counts every tap of a SAME-padded layer, useful_flops only the
+        products that meet data (flops * ctx_prof_entry.useful_frac)."""
         ents = (_lib.CtxProfEntry * 256)()
         n = ctypes.c_int()
         self._ck(self._lib.ctx_profile_step(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx), ctypes.c_void_p(d_tgt),
                                             B, float(lr), iters, ents, 256, ctypes.byref(n)))
-        return [dict(name=e.name.decode(), kernel=e.kernel.decode(), flops=e.flops, ms=e.ms) for e in ents[: n.value]]
+        return [dict(name=e.name.decode(), kernel=e.kernel.decode(), flops=e.flops, ms=e.ms, useful_flops=e.flops * e.useful_frac)
+                for e in ents[: n.value]]
 
     @staticmethod
     def kernel_table(entries):
-        """Groups profile_step entries by kernel: {kernel: dict(ms, flops, launches)}, ms-descending."""
+        """Groups profile_step entries by kernel: {kernel: dict(ms, flops, useful_flops, launches)}, ms-descending."""
         tab = {}
         for e in entries:
-            t = tab.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, launches=0))
+            t = tab.setdefault(e["kernel"], dict(ms=0.0, flops=0.0, useful_flops=0.0, launches=0))
             t["ms"] += e["ms"]
             t["flops"] += e["flops"]
+            t["useful_flops"] += e.get("useful_flops", e["flops"])
             t["launches"] += 1
         return dict(sorted(tab.items(), key=lambda kv: -kv[1]["ms"]))
 

@@ -262,6 +262,19 @@ int ctx_dp_allreduce_grads(ctx_handle* h);
 int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B, float lr,
                       float scalars[4]);
 int ctx_dp_scalars(ctx_handle* h, float scalars[4]);
+/* The trainer's loop on N GPUs without a host gather (scripts/train_script.py:153-167 + SURVEY.md 8e / 8f-3): every rank holds the
+ * whole demo tensor in HBM (ctx_demos_upload) and is handed the SAME global index arrays choicesrc / choicetgt [B_global]
+ * (np.random.choice(ntrain, batch_size) twice, :154-155; B_global a multiple of the world size, B_global / world <= max_batch).
+ * Rank r gathers rows b in [r B/world, (r+1) B/world) of the global batch on the device -- src[b] = vdata[b % T][choicesrc[b]],
+ * tgt[b] = vdata[b % T][choicetgt[b]], ctx[b] = vdata[0][choicetgt[b]], b the GLOBAL row -- and runs ctx_dp_train_step's bucketed
+ * schedule on them: N ranks leave the parameters a single handle's ctx_train_step_sampled leaves on the same arrays (up to f32
+ * summation order).  scalars (nullable): the GLOBAL {loss, simloss, recon1, recon2}.
+ * ctx_dp_eval_sampled: the validation fetch (:169-176) sharded the same way -- forward + losses on this rank's rows, GLOBAL scalars
+ * (collective: every rank must call it), out / out2 (nullable) = THIS RANK's rows [B_global / world, H, W, 3]. */
+int ctx_dp_train_step_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B_global, float lr,
+                              float scalars[4]);
+int ctx_dp_eval_sampled(ctx_handle* h, const int32_t* choicesrc, const int32_t* choicetgt, int B_global, float scalars[4], float* out,
+                        float* out2);
 /* In-place SUM over the ranks of a HOST buffer of doubles (synchronous; through a device staging buffer and ncclAllReduce
  * on the handle's collective stream).  For the sharded demo cache of the reward hook (sampler/base.py:195-223 builds it on
  * one device; reward.py shards the demo videos rank::world and adds the partial feature / frame sums): the group that
@@ -271,14 +284,17 @@ int ctx_dp_allreduce_host_f64(ctx_handle* h, double* buf, size_t n);
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* One entry per launch group of a train step (a layer's forward, input gradient, filter gradient,
  * bias gradient, the losses, Adam): HIP-event time on the handle's stream, averaged over `iters`
- * full steps, plus the group's algorithmic FLOPs (2 per multiply-add, all 25 taps) and the kernel
- * that executes it.  bench.py derives its `roofline` block from this. */
+ * full steps, plus the group's algorithmic FLOPs (2 per multiply-add, all 25 taps), the share of them that
+ * is not a product with SAME padding (useful_frac) and the kernel that executes it.  bench.py derives its
+ * `roofline` block from this. */
 typedef struct ctx_prof_entry {
     char name[56];
     char kernel[40];
-    double flops;
+    double flops;       /* 2 per multiply-add, every tap of a SAME-padded layer counted (SURVEY.md 8d's convention) */
     float ms;
-    float reserved;
+    float useful_frac;  /* share of `flops` whose product meets data on both sides: (valid (position, tap) pairs) / (all) of the
+                           layer -- (5n-3)^2 / (5n)^2 for a 5x5 stride-2 layer with an n x n small grid; 1 for linear layers.
+                           flops * useful_frac is what a kernel that never multiplies padding zeros has to do. */
 } ctx_prof_entry;
 int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B,
                      float lr, int iters, ctx_prof_entry* entries, int max_entries, int* n_entries);

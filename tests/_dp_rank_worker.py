@@ -11,6 +11,34 @@ sys.path.insert(0, ROOT)
 
 H = W = 32
 D, F, SHARD, LR, PSEED = 32, 128, 8, 1e-3, 321
+NLEN, NDEMO = 4, 6          # (e): the trainer's sampler -- demo tensor [NLEN, NDEMO, H, W, 3], global batch SHARD * world
+
+
+def exchange_uid(work, tag, rank):
+    """rank 0 makes a rendezvous blob (ctx_dp_unique_id) and publishes it through the work directory"""
+    from imitation_from_observation_amd import Translator
+    idfile = os.path.join(work, tag)
+    if rank == 0:
+        uid = Translator.dp_unique_id()
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+        return uid
+    t0 = time.time()
+    while not os.path.exists(idfile):
+        if time.time() - t0 > 60:
+            raise SystemExit(f"rank 0 never published {tag}")
+        time.sleep(0.01)
+    return open(idfile, "rb").read()
+
+
+def demo_tensor():
+    return np.random.default_rng(29).integers(0, 256, (NLEN, NDEMO, H, W, 3), dtype=np.uint8)
+
+
+def sampled_choices(world, steps=3):
+    rng = np.random.default_rng(31)
+    return [(rng.integers(0, NDEMO, SHARD * world), rng.integers(0, NDEMO, SHARD * world)) for _ in range(steps)]
 
 
 def full_batch(world):
@@ -123,6 +151,39 @@ def main():
     tra.sync()
     out["abl_grads"] = tra.get_grads_flat()
     tra.close()
+    # (e) the trainer's loop body on two ranks (ctx_dp_train_step_sampled / ctx_dp_eval_sampled): every rank holds the demo tensor and is
+    # handed the SAME global index arrays; it gathers its own rows of the global batch (t = b % T on the global row).  Rank 0 also runs
+    # the single-handle ctx_train_step_sampled on the same arrays: the parameters must agree up to f32 summation order.
+    trs = Translator(H, W, D, F, max_batch=SHARD)
+    trs.set_params(p)
+    trs.dp_init(exchange_uid(work, "uid4.bin", rank), rank, world)
+    trs.load_demos(demo_tensor())
+    choices = sampled_choices(world)
+    ssc = []
+    for cs, ct in choices:
+        sc = trs.dp_train_step_sampled(cs, ct, lr=1e-4)
+        ssc.append([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]])
+    out["samp_scalars"] = np.array(ssc, np.float64)
+    trs.sync()
+    out["samp_params3"] = trs.get_params_flat()
+    ev = trs.dp_eval_sampled(*choices[0])
+    out["samp_eval"] = np.array([ev["loss"], ev["simloss"], ev["recon1"], ev["recon2"]], np.float64)
+    out["samp_eval_out"] = ev["out"]
+    trs.close()
+    if rank == 0:
+        solo = Translator(H, W, D, F, max_batch=SHARD * world)
+        solo.set_params(p)
+        solo.load_demos(demo_tensor())
+        ssc = []
+        for cs, ct in choices:
+            sc = solo.train_step_sampled(cs, ct, lr=1e-4)
+            ssc.append([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]])
+        out["solo_scalars"] = np.array(ssc, np.float64)
+        out["solo_params3"] = solo.get_params_flat()
+        ev = solo.eval_sampled(*choices[0])
+        out["solo_eval"] = np.array([ev["loss"], ev["simloss"], ev["recon1"], ev["recon2"]], np.float64)
+        out["solo_eval_out"] = ev["out"]
+        solo.close()
     np.savez(os.path.join(work, f"rank{rank}.npz"), **out)
     tr.close()
     print(f"rank {rank} ok", flush=True)

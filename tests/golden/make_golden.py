@@ -380,6 +380,19 @@ def make_ref299():
         fx[k + "_keep"] = res[k][list(REF299_KEEP)].astype(np.float32)
         flat = res[k].reshape(B, -1)
         fx[k + "_rows"] = np.stack([flat.sum(1), np.abs(flat).sum(1), np.sqrt((flat * flat).sum(1))], 1)
+    # lrelu'-relevant activations in the device's buffer order (a_k = [tgt | src | ctx] over 3B images, e_k = [pass 1 | pass 2]): negative
+    # entries and entries within 1e-6 of zero (relative to the buffer's max) -- the candidates an f32 pass may put on the other side
+    bufs = {f"a{k}": np.concatenate([c["e_tgt"][k], c["e_src"][k], c["e_ctx"][k]]) for k in range(5)}
+    bufs["z"] = np.concatenate([c["e_tgt"][5], c["e_src"][5], c["e_ctx"][5]])
+    bufs["th0"] = c["trans_h0"]
+    bufs["dz"] = np.concatenate([c["d1"][0], c["d2"][0]])
+    for k in (1, 2, 3):
+        bufs[f"e{k}"] = np.concatenate([c["d1"][k], c["d2"][k]])
+    fx["act_names"] = np.array(sorted(bufs))
+    fx["act_negative"] = np.array([int((bufs[k] < 0).sum()) for k in sorted(bufs)], np.int64)
+    fx["act_near_zero"] = np.array([int((np.abs(bufs[k]) <= 1e-6 * np.abs(bufs[k]).max()).sum()) for k in sorted(bufs)], np.int64)
+    fx["act_size"] = np.array([bufs[k].size for k in sorted(bufs)], np.int64)
+    del bufs
     g = ci.backward(p, c, cfg)
     print(f"backward {time.time() - t0:.0f}s", flush=True)
     probes = ref299_probes([(n, g[n].size) for n in names])

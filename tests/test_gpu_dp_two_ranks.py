@@ -128,3 +128,23 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
         a, b = z[0]["abl_grads"][off:off + n].astype(np.float64), ag[off:off + n]
         assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 1e-12, (name, np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
         off += n
+    # ---- the trainer's sampled step on two ranks (ctx_dp_train_step_sampled: each rank gathers its rows of the global batch from its
+    # resident demo tensor) against ONE handle's ctx_train_step_sampled on the same index arrays
+    np.testing.assert_array_equal(z[0]["samp_params3"], z[1]["samp_params3"])                    # replicas bit-identical
+    np.testing.assert_array_equal(z[0]["samp_scalars"], z[1]["samp_scalars"])
+    np.testing.assert_allclose(z[0]["samp_scalars"][:, [0, 2, 3]], z[0]["solo_scalars"][:, [0, 2, 3]], rtol=2e-5)
+    np.testing.assert_allclose(z[0]["samp_scalars"][:, 1], z[0]["solo_scalars"][:, 1], rtol=2e-3)  # simloss: see above
+    a, b = z[0]["samp_params3"].astype(np.float64), z[0]["solo_params3"].astype(np.float64)
+    dev = np.abs(a - b)
+    print("sampled DP vs one handle after 3 steps: max |dp| / max |p| =", dev.max() / np.abs(b).max(), " rel-L2 =", np.linalg.norm(a - b) / np.linalg.norm(b),
+          " entries beyond 1e-6 of max |p|:", int((dev > 1e-6 * np.abs(b).max()).sum()), "of", a.size)
+    # (Adam's first steps move every entry by ~lr whatever the size of its gradient, so an entry whose two f32 gradients differ in
+    # sign -- a gradient at the rounding floor -- ends 2 lr apart: those are counted, everything else agrees to 1e-6)
+    assert (dev > 1e-6 * np.abs(b).max()).mean() <= 1e-4
+    assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+    # the sharded validation fetch: global scalars, and the two ranks' rows side by side = the single handle's outputs
+    np.testing.assert_array_equal(z[0]["samp_eval"], z[1]["samp_eval"])
+    both = np.concatenate([z[0]["samp_eval_out"], z[1]["samp_eval_out"]])
+    assert both.shape == z[0]["solo_eval_out"].shape
+    assert np.abs(both - z[0]["solo_eval_out"]).max() <= 1e-4 * np.abs(z[0]["solo_eval_out"]).max()
+    np.testing.assert_allclose(z[0]["samp_eval"][[0, 2, 3]], z[0]["solo_eval"][[0, 2, 3]], rtol=1e-4)

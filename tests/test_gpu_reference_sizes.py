@@ -104,6 +104,20 @@ def test_inception2_at_8x8x2048_batch25_against_the_float64_fixture(T):
         # Adam step 1 (train_script.py:163): scalars before the update, the gradient it used
         sc = tr.train_step(src, ctx, tgt, lr=float(z["lr"]))
         assert abs(sc["loss"] - z["train_scalars"][0][0]) <= 1e-5 * z["train_scalars"][0][0]
+        # lrelu' branches.  An f32 pass puts a few of the ~3e6 activations that sit within rounding of zero on the other side of the kink
+        # than float64 does, and each one moves 0.8 dy of one (image, position, channel) into every gradient upstream of it (first box
+        # run: conv/h0..h2 2e-3 off the fixture with everything downstream of h2 at 1e-4).  So the gradients are compared twice:
+        # (1) with the FIXTURE as it is -- whole-tensor bounds that hold with the flips in; (2) with the float64 oracle re-run here on
+        # the same inputs, its saved activations given the device's sign at exactly the flipped elements (tests/_align.py) -- tight.
+        gold = {str(n): (int(a), int(b), int(c)) for n, a, b, c in zip(z["act_names"], z["act_negative"], z["act_near_zero"], z["act_size"])}
+        delta = {}
+        for buf in ("a0", "a1", "a2", "a3", "a4", "th0", "dz", "e1", "e2", "e3"):
+            neg, near, size = gold[buf]
+            delta[buf] = (int((tr.debug_read(buf, size) < 0).sum()) - neg, near)
+        zall = tr.debug_read("Z", 4 * B * cfg.featsize).reshape(4, B, -1)               # [trans_z | tgt_z | src_z | ctx_z]
+        delta["z"] = (int((zall[1:] < 0).sum()) - gold["z"][0], gold["z"][1])
+        print("lrelu' branch report (buffer: net sign changes vs float64, candidates within 1e-6 of zero):", delta)
+        assert all(abs(d) <= max(8, near) for d, near in delta.values()), delta          # a wrong activation would move thousands
         gg = tr.get_grads()
         probes = mg.ref299_probes([(n, int(np.prod(gg[n].shape))) for n in names])
         report = {}
@@ -116,13 +130,27 @@ def test_inception2_at_8x8x2048_batch25_against_the_float64_fixture(T):
             proj = float(np.sqrt(np.mean((mg.ref299_project(a, seed) - z["grad_proj"][i]) ** 2)) / gnorm)
             nrm = abs(float(np.sqrt((a * a).sum())) - gnorm) / gnorm
             report[n] = (samp, proj, nrm)
-        print("gradient deviation per tensor (rel-L2 on 1024 samples, projected rel-L2 of the whole tensor, |norm| deviation):",
+        print("gradient deviation per tensor vs the fixture (rel-L2 on 1024 samples, projected rel-L2 of the whole tensor, |norm| deviation):",
               {k: tuple(float(f"{x:.1e}") for x in v) for k, v in report.items()})
         for n, (samp, proj, nrm) in report.items():
             tight = n.startswith("deconv/d_h4")                                         # upstream of every lrelu' mask
-            assert samp <= (1e-5 if tight else 2e-3), (n, samp, proj, nrm)
+            assert samp <= (1e-5 if tight else 1e-2), (n, samp, proj, nrm)
             assert proj <= (1e-5 if tight else 3e-3), (n, samp, proj, nrm)
             assert nrm <= (1e-5 if tight else 1e-3), (n, samp, proj, nrm)
+        # (2) the oracle re-run with the device's branches
+        from tests._align import align_gen_cache
+        p64 = {k: v.astype(np.float64) for k, v in p32.items()}
+        res, c = ci.forward(p64, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+        np.testing.assert_allclose([res["loss"], res["simloss"], res["recon1"], res["recon2"]], z["scalars"], rtol=1e-12)
+        nflip, worst, where = align_gen_cache(tr, c, B)
+        print(f"aligned {nflip} activations (largest |x| / max|x| among them {worst:.1e}) in {where}")
+        assert nflip <= 64 and worst <= 1e-5
+        g = ci.backward(p64, c, cfg)
+        del p64, c
+        worst_t = {n: relmax(gg[n], g[n]) for n in names}
+        print("gradients vs the branch-aligned oracle, max-norm relative:", {k: float(f"{v:.1e}") for k, v in worst_t.items()})
+        assert max(worst_t.values()) <= 2e-4, worst_t
+        del g, gg
         # the step after the update: the loss fell by what the oracle's float64 Adam step takes off (4.5e7 -> 1.8e7)
         sc2 = tr.train_step(src, ctx, tgt, lr=float(z["lr"]))
         want = z["train_scalars"][1]
