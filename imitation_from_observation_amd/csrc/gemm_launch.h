@@ -69,9 +69,10 @@ static void launch_128(hipStream_t s, const LA& a, const LB& b, const Epi& ep, i
     }
 }
 
+// prob_weight (optional, nprob entries): relative length of each problem -- the launcher then runs them in balanced_order
 template <class LA, class LB, bool BIG = false, int W32 = 1, int WSP = 0>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
-                         SplitWs ws, int max_chunks = 0) {
+                         SplitWs ws, int max_chunks = 0, const int* prob_weight = nullptr) {
     static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
     if constexpr (BIG) {
         const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
@@ -126,6 +127,13 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
+    {   // problems of unequal length behind the XCD swizzle: balanced runs per XCD (launch.h: balanced_order).  The 8 XCDs share the
+        // nsplit x nprob slots in order, so one split's problems are spread over 8 / nsplit of them.  CTX_BALANCE=0: plain order.
+        if (prob_weight && ep.xcd_swizzle && !ep.swz_group && nprob >= 8) {
+            const int nbins = nsplit <= 1 ? 8 : 8 % nsplit == 0 ? 8 / nsplit : 1;
+            ep.perm = balanced_order(prob_weight, nprob, nbins);
+        }
+    }
     // narrow operands (ContextAEReal's 32-channel layers): tiles that do not multiply zeros.  f32 only.
     if (!ws.prec && N <= 32 && M > 64) launch_tile_f32<LA, LB, 1, 1, 4, 1>(s, a, b, ep, M, N, nprob, nsplit);          // 128 x 32
     else if (!ws.prec && N <= 32 && M <= 32) launch_tile_f32<LA, LB, 1, 1, 1, 1>(s, a, b, ep, M, N, nprob, nsplit);    //  32 x 32

@@ -27,14 +27,23 @@ static int rect_max_chunks(const RectGeo& g) {
         for (int kx = 0; kx < g.K; ++kx) { const int64_t c = (int64_t)g.rh[ky] * g.rw[kx] * g.ipc; if (c > t) t = c; }
     return (int)t;
 }
+// positions per tap: the lengths of the 25 problems (launch.h: balanced_order)
+static void rect_weights(const RectGeo& g, int wt[25]) {
+    for (int ky = 0; ky < g.K; ++ky)
+        for (int kx = 0; kx < g.K; ++kx) wt[ky * g.K + kx] = g.rh[ky] * g.rw[kx];
+}
 int xcd_swz();
 void conv_wgrad_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmallR& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
-    launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g));
+    int wt[25];
+    rect_weights(a.g, wt);
+    launch_igemm<NmWgradBigR, NmWgradSmallR, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g), (balance_bits() & 4) ? wt : nullptr);
 }
 void conv_wgrad2_r(hipStream_t s, const NmWgradBigR& a, const NmWgradSmall2R& b, Epi ep, int M, int N, SplitWs ws) {
     ep.prob_stride = (int64_t)M * N; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 2) & 1;
-    launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g));
+    int wt[25];
+    rect_weights(a.g, wt);
+    launch_igemm<NmWgradBigR, NmWgradSmall2R, false, 1, 2>(s, a, b, ep, M, N, a.g.K * a.g.K, rect_avg_chunks(a.g), ws, rect_max_chunks(a.g), (balance_bits() & 4) ? wt : nullptr);
 }
 void conv3_wgrad(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 2;

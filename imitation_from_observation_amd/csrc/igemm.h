@@ -119,6 +119,8 @@ struct Epi {
     int xcd_swizzle = 0;            // 1: consecutive work items go to the SAME XCD (its L2): block b does item (b % 8) * ceil(T/8) + b / 8
     int swz_group = 0;              // != 0 (multiple of 8): the swizzle is applied inside consecutive groups of this many items, so
                                     // all XCDs work on the same group (a parity class of a transposed conv) at the same time
+    const uint16_t* perm = nullptr; // != null: problem slot pr runs problem perm[pr] (device memory, nprob entries): the launcher's
+                                    // load-balanced order for problems of unequal length (gemm_launch.h: balanced_order)
 };
 
 // returns false if the row has no destination
@@ -1091,7 +1093,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const LA la, const 
     // transposed conv (nprob == 4): parity classes have 4/6/6/9 taps.  Dispatching 9,6,4,6 makes the two
     // blocks that share a CU (one from each half of a 2-per-CU round) sum to 13 and 12 taps, not 15 and 10.
     const int pr = rest % nprob;
-    const int prob = nprob == 4 ? ((0x3201 >> (4 * (3 - pr))) & 15) : nprob - 1 - pr;
+    const int prob = ep.perm ? (int)ep.perm[pr] : nprob == 4 ? ((0x3201 >> (4 * (3 - pr))) & 15) : nprob - 1 - pr;
     const int split = rest / nprob;
     const int m0 = bx * TM, n0 = by * TN;
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
     const int bx = rest % gm; rest /= gm;
     const int by = rest % gn; rest /= gn;
     const int pr = rest % nprob;
-    const int prob = nprob == 4 ? ((0x3201 >> (4 * (3 - pr))) & 15) : nprob - 1 - pr;
+    const int prob = ep.perm ? (int)ep.perm[pr] : nprob == 4 ? ((0x3201 >> (4 * (3 - pr))) & 15) : nprob - 1 - pr;
     const int split = rest / nprob;
     const int m0 = bx * TM, n0 = by * TN;
 

@@ -4,6 +4,8 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
+#include <algorithm>
 #include <cstdio>
 #include "launch.h"
 
@@ -39,6 +41,50 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
         (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         have = bytes;
     }
+}
+
+int balance_bits() { static const int v = [] { const char* e = getenv("CTX_BALANCE"); return e ? atoi(e) : 1; }(); return v; }
+
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins) {
+    if (nprob <= 1 || nprob > 65535 || nbins < 1) return nullptr;
+    static std::mutex mu;
+    static std::map<std::pair<int, std::vector<int>>, uint16_t*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<int> key(weight, weight + nprob);
+    key.push_back(nbins);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find({dev, key});
+    if (it != cache.end()) return it->second;
+    // longest-first greedy into nbins runs of at most ceil(nprob / nbins) problems
+    std::vector<int> idx(nprob);
+    for (int i = 0; i < nprob; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return weight[a] > weight[b]; });
+    const int cap = (nprob + nbins - 1) / nbins;
+    std::vector<std::vector<int>> bins(nbins);
+    std::vector<int64_t> sum(nbins, 0);
+    for (int p : idx) {
+        int best = -1;
+        for (int b = 0; b < nbins; ++b)
+            if ((int)bins[b].size() < cap && (best < 0 || sum[b] < sum[best])) best = b;
+        bins[best].push_back(p);
+        sum[best] += weight[p];
+    }
+    // inside a run: heaviest, lightest, second heaviest, second lightest, ... (each bin is sorted heavy -> light by construction)
+    std::vector<uint16_t> order;
+    order.reserve(nprob);
+    for (int b = 0; b < nbins; ++b) {
+        int lo = 0, hi = (int)bins[b].size() - 1;
+        while (lo <= hi) {
+            order.push_back((uint16_t)bins[b][lo++]);
+            if (lo <= hi) order.push_back((uint16_t)bins[b][hi--]);
+        }
+    }
+    uint16_t* d = nullptr;
+    if (hipMalloc((void**)&d, nprob * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, order.data(), nprob * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    cache[{dev, key}] = d;
+    return d;
 }
 
 namespace { thread_local char g_launch_err[256]; thread_local bool g_launch_err_set = false; }

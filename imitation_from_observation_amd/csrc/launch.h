@@ -19,6 +19,19 @@ bool take_launch_error(char* buf, size_t n);       // true (and the message, cle
 struct DevInfo { int cus; int lds_per_cu; };
 const DevInfo& dev_info();
 void ensure_dyn_lds(const void* kernel, size_t bytes);
+// Load-balanced problem order for launches whose problems differ in length (position-major convolutions: 9 .. 25 taps per position on
+// a 4x4 grid; rectangle-ordered filter gradients: 9/16 .. 16/16 of the positions per tap).  With the XCD swizzle an XCD runs a
+// CONTIGUOUS run of problem slots and a launch of about one round of resident blocks ends with its slowest XCD: in row-major order
+// the 4x4 conv's XCDs get 24 .. 45 taps (mean 36), i.e. the launch runs at 80 %.  balanced_order deals the problems to `nbins` runs
+// of (nearly) equal length by longest-first greedy, heavy and light alternating inside a run (the two blocks that share a CU come
+// from different parts of the run), and returns the order as a DEVICE array of nprob uint16 (cached per weight vector and device;
+// created on first use -- a synchronous 2 * nprob-byte copy).  Same problems, same arithmetic per problem: results do not change.
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins);
+// CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (default: the
+// 4x4 layers, two positions per XCD -- d_h1's input gradient 0.675 -> 0.587 ms); 2 = on larger grids too (8x8: a contiguous run of
+// positions is a grid row whose blocks share input pixels in the XCD's L2 -- scattering them cost more than the 7.5 % imbalance);
+// 4 = the rectangle-ordered filter gradient's 25 taps.
+int balance_bits();
 
 // Split-K policy shared by all launchers: `slab` is scratch of `slab_floats` floats.
 struct SplitWs {

@@ -299,6 +299,258 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row blocks (round 4): the same layer with the y direction's products on SAME padding never formed.
+//
+// `wconvt_kernel` forms all 25 taps at every position; on a 4x4 / 8x8 grid 28 % / 14 % of those products read the zero halo (a
+// whole-step A/B with the loop cut to 18 / 21 taps -- wrong results, right amount of work -- put the ceiling of skipping them at
+// -0.37 / -0.59 ms of the 13.4 ms step; profiles/round4_a_ab_upper_bounds.txt).  An MFMA's 32 columns are 32 POSITIONS, so a tap can
+// only be dropped where it is invalid for all of them.  Here a block owns ONE GRID ROW r of 64 / WS images (64 positions per parity
+// class) x 64 output channels, so "tap (dy, dx) reads input row r + dy" is block-uniform: a block of row 0 runs the 15 taps with
+// dy >= 0, one of the last row the 20 with dy <= 0, interior rows all 25 -- (15 + 20 + 25 (HS - 2)) / (25 HS) of the products:
+// 85 % on 4x4, 92.5 % on 8x8 (the exact counts are 72.25 % / 85.6 %: the x direction's halo products are still formed, its
+// validity varies inside an MFMA's columns).  The tap list of a row type is compile time (three bodies behind one switch), so the
+// loop keeps the literal LDS offsets and the woven filter ring of the kernel above.
+//   * 4 waves = 2 position halves x 2 channel halves (32 x 32 each, 64 accumulator registers per wave);
+//   * LDS: input rows r-1, r, r+1 of the images (rows outside the image are never read, the x halo holds zeros) 41 KB + filter
+//     ring 2 x 64 x 36 floats 18 KB: two blocks per CU;
+//   * the same FLOPs per filter byte as the 128 x 32 tiles the 4x4 launches used, twice as many per staged input byte;
+//   * an image group's rows and column tiles are dealt to ONE XCD (they share input rows).
+// Two tile shapes (PB = positions per block):
+//   PB = 64  : 64 / WS images of the row x 64 channels; waves = 2 position halves x 2 channel halves; input rows with a zero pixel on
+//              either side (pitch WS + 2; 12 on 8-wide rows for the bank map), 41 KB + filter ring 18 KB.
+//   PB = 128 : 128 / WS images of the row x 32 channels; waves = 4 position groups -- the filter bytes per FLOP of wconvt_kernel's
+//              128-position tiles (they go with 1 / PB; at PB = 64 the 512-image 4x4 launches ran no faster with 15 % fewer MFMAs:
+//              L2 -> LDS traffic).  Input rows PACKED: pitch WS + 1, the one zero slot between two rows serves as the right halo of
+//              the row before and the left halo of the row after (+ one leading zero slot): 69 KB + filter ring 9 KB, two blocks per
+//              CU inside the 160 KB.
+__host__ __device__ constexpr bool wr_valid(int t, int RT) { return RT == 0 ? tap_info(t).dy >= 0 : RT == 2 ? tap_info(t).dy <= 0 : true; }
+__host__ __device__ constexpr int wr_count(int RT) { int n = 0; for (int t = 0; t < 25; ++t) n += wr_valid(t, RT) ? 1 : 0; return n; }
+__host__ __device__ constexpr int wr_tap(int RT, int n) {          // the n-th valid tap of the row type (n taken modulo their number)
+    n %= wr_count(RT);
+    for (int t = 0; t < 25; ++t)
+        if (wr_valid(t, RT)) { if (n == 0) return t; --n; }
+    return 0;
+}
+
+template <int WS, int PB>
+struct WrGeo {
+    static constexpr bool PACK = PB == 128;
+    static constexpr int IMGT = PB / WS, HP = 3;
+    static constexpr int WPL = PACK ? WS + 1 : (WS == 8 ? 12 : WS + 2), LEAD = PACK ? 1 : 0;
+    static constexpr int TPIX = LEAD + IMGT * HP * WPL;
+    static constexpr int COLS = PB == 128 ? 32 : 64;                     // output channels per block
+    static constexpr size_t lds = (size_t)(TPIX * WC_LDP + 2 * COLS * WC_LDP) * sizeof(float);
+};
+
+// lane -> (image of the tile, column) of the lane's position.  A ds_read_b128 lane group ({0-3,12-15,20-27} / the rest) must hit 16 pixel
+// slots that are distinct mod 16:
+//   PB = 64, WS = 8 (image stride 36 slots): a group = two images two apart (72 = 8 mod 16); WS = 4 (stride 18): four images two apart
+//   (0, 36, 72, 108 = 0, 4, 8, 12 mod 16);  PB = 128, WS = 4 (packed, stride 15 = -1 mod 16): wave w takes images w + 4 k, a group =
+//   k = 0..3 or 4..7 (slots 0, -4, -8, -12 mod 16).
+template <int WS, int PB>
+__device__ __forceinline__ void wr_lane_pos(int wv, int row, int& il, int& pj) {
+    const bool ga = row < 4 || (row >= 12 && row < 16) || (row >= 20 && row < 28);
+    const int k = ga ? (row < 4 ? row : row < 16 ? row - 8 : row - 12) : (row < 12 ? row - 4 : row < 20 ? row - 8 : row - 16);   // 0..15 inside the group
+    pj = k % WS;
+    if constexpr (PB == 128) il = wv + 4 * (k / WS + (ga ? 0 : 16 / WS));
+    else il = (wv & 1) * (32 / WS) + (k / WS) * 2 + (ga ? 0 : 1);
+}
+
+template <int HS, int WS, int RT, int PB>
+__device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int r, int n0) {
+    using G = WrGeo<WS, PB>;
+    constexpr int IMGT = G::IMGT, HP = G::HP, WPL = G::WPL, TPIX = G::TPIX, LEAD = G::LEAD, COLS = G::COLS;
+    constexpr int NPA = (TPIX * 8 + WC_THREADS - 1) / WC_THREADS;
+    constexpr int BSTAGE = COLS * WC_LDP, NPB = COLS * 8 / WC_THREADS;
+    constexpr int NT = wr_count(RT);
+    static_assert(NPA <= 2 * NT && NPB >= 1, "at most two input float4 of the next slice per tap");
+    float* sA = smem;
+    float* sB = smem + TPIX * WC_LDP;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    const int wc = PB == 64 ? wv >> 1 : 0;                                // channel half (PB = 64)
+    const int cb = P.c1 + P.c2, ns1 = P.c1 >> 5, nslice = cb >> 5;
+    const rsrc_t rs1 = make_rsrc(P.s1), rs2 = make_rsrc(P.s2 ? P.s2 : P.s1);
+
+    // pixel slot hp of the tile: [LEAD zero slots] then (image, row slot 0..2 = input row r - 1 + slot, x slot); data column x sits at
+    // x slot x + 1 (plain) / x (packed: x slot WS is the shared zero)
+    auto a_load = [&](int slice, int p) -> float4 {
+        const int f = tid + WC_THREADS * p;
+        const int hp = (f >> 3) - LEAD, k4 = (f & 7) * 4;
+        const int il = hp / (HP * WPL), q = hp - il * (HP * WPL), y = r + q / WPL - 1, x = q - (q / WPL) * WPL - (G::PACK ? 0 : 1);
+        const int img = img0 + il;
+        const bool ok = hp >= 0 && f < TPIX * 8 && (unsigned)y < (unsigned)HS && (unsigned)x < (unsigned)WS && img < P.nimg;
+        const bool second = slice >= ns1;
+        const int im = second ? img % P.nmod2 : img;
+        const int ld = second ? P.c2 : P.c1, kc = (second ? slice - ns1 : slice) * 32;
+        const uint32_t v = (uint32_t)(((im * HS + y) * WS + x) * ld + kc + k4) * 4u;
+        return bload4(second ? rs2 : rs1, ok ? v : OOB);
+    };
+    auto a_store = [&](int p, float4 v) {
+        const int f = tid + WC_THREADS * p;
+        if (f < TPIX * 8) *reinterpret_cast<float4*>(&sA[(f >> 3) * WC_LDP + (f & 7) * 4]) = v;
+    };
+    const int bk4 = (tid & 7) * 4;
+    uint32_t bvoff[NPB];
+#pragma unroll
+    for (int p = 0; p < NPB; ++p) {
+        const int row = (tid >> 3) + 32 * p;
+        bvoff[p] = n0 + row < P.ca ? (uint32_t)((n0 + row) * cb + bk4) * 4u : OOB;
+    }
+    auto b_load = [&](int slice, int tapw, float4 (&v)[NPB]) {
+        if (slice >= nslice) slice = nslice - 1;
+        const rsrc_t rr = make_rsrc(P.w + ((int64_t)tapw * P.ca) * cb + slice * 32);
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) v[p] = bload4(rr, bvoff[p]);
+    };
+    auto b_store = [&](int stage, const float4 (&v)[NPB]) {
+#pragma unroll
+        for (int p = 0; p < NPB; ++p) *reinterpret_cast<float4*>(&sB[stage * BSTAGE + ((tid >> 3) + 32 * p) * WC_LDP + bk4]) = v[p];
+    };
+
+    // the lane's position (image il of the tile, column pj of grid row r); base = the slot of input pixel (r - 1, pj - 1), so that tap
+    // (dy, dx) is the literal offset ((dy + 1) WPL + dx + 1) slots
+    int il, pj;
+    wr_lane_pos<WS, PB>(wv, l31, il, pj);
+    const float* aBase = sA + (LEAD + il * HP * WPL + pj - (G::PACK ? 1 : 0)) * WC_LDP + 4 * h;
+    const float* bBase = sB + (32 * wc + l31) * WC_LDP + 4 * h;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[c][q] = 0.f;
+
+    float4 areg[NPA], breg[NPB];
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) areg[p] = a_load(0, p);
+    b_load(0, tap_info(wr_tap(RT, 0)).ky * 5 + tap_info(wr_tap(RT, 0)).kx, breg);
+#pragma unroll
+    for (int p = 0; p < NPA; ++p) a_store(p, areg[p]);
+    b_store(0, breg);
+    b_load(0, tap_info(wr_tap(RT, 1)).ky * 5 + tap_info(wr_tap(RT, 1)).kx, breg);
+    __syncthreads();
+
+    for (int s = 0; s < nslice; ++s) {
+        const int snext = s + 1 < nslice ? s + 1 : s;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const TapInfo ti = tap_info(wr_tap(RT, n));
+            const int stage = (s * NT + n) & 1;
+            const float* aT = aBase + ((ti.dy + 1) * WPL + (ti.dx + 1)) * WC_LDP;
+            const float* bT = bBase + stage * BSTAGE;
+            float4 a[2], b[2];
+            a[0] = *reinterpret_cast<const float4*>(aT);
+            b[0] = *reinterpret_cast<const float4*>(bT);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q < 3) {
+                    a[(q + 1) & 1] = *reinterpret_cast<const float4*>(aT + 8 * (q + 1));
+                    b[(q + 1) & 1] = *reinterpret_cast<const float4*>(bT + 8 * (q + 1));
+                }
+                const float av[4] = {a[q & 1].x, a[q & 1].y, a[q & 1].z, a[q & 1].w};
+                const float bv[4] = {b[q & 1].x, b[q & 1].y, b[q & 1].z, b[q & 1].w};
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) acc[ti.cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tt], av[tt], acc[ti.cls], 0, 0, 0);
+                if (q == 0) b_store(stage ^ 1, breg);
+                if (q == 1) {
+                    const TapInfo tj = tap_info(wr_tap(RT, n + 2));
+                    b_load(n + 2 < NT ? s : s + 1, tj.ky * 5 + tj.kx, breg);
+                }
+                if (q == 2 && n < NPA) areg[n] = a_load(snext, n);
+                if (q == 3 && n + NT < NPA) areg[n + NT] = a_load(snext, n + NT);
+            }
+            __syncthreads();
+        }
+        if (s + 1 < nslice) {
+#pragma unroll
+            for (int p = 0; p < NPA; ++p) a_store(p, areg[p]);
+            __syncthreads();
+        }
+    }
+
+    // epilogue: as in wconvt_kernel (column = the lane's position, registers 4g .. 4g + 3 = channels 8g + 4h .. + 3)
+    const Epi& e = P.ep;
+    const int img = img0 + il;
+    const bool rowok = img < P.nimg;
+    const rsrc_t rm = make_rsrc(e.mask ? e.mask : P.s1), r1 = make_rsrc(e.add1 ? e.add1 : P.s1), r2 = make_rsrc(e.add2 ? e.add2 : P.s1);
+    const float leak = e.lrelu == 2 ? 0.f : LEAK;
+    const int nn = n0 + 32 * wc + 4 * h;
+    float4 bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = e.bias ? ldg4(e.bias + nn + 8 * g) : zero4();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const uint32_t pix = (uint32_t)((img * (2 * HS) + 2 * r + py) * (2 * WS) + 2 * pj + px);
+        const uint32_t pa = (e.add1_mod && (int64_t)pix >= e.add1_mod) ? pix - (uint32_t)e.add1_mod : pix;
+        float4 mk[4], a1[4], a2[4];
+        if (e.mask) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mk[g] = bload4(rm, rowok ? (pix * (uint32_t)e.ldm + nn + 8 * g) * 4u : OOB);
+        }
+        if (e.add1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a1[g] = bload4(r1, rowok ? (pa * (uint32_t)e.lda1 + nn + 8 * g) * 4u : OOB);
+        }
+        if (e.add2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a2[g] = bload4(r2, rowok ? (pix * (uint32_t)e.lda2 + nn + 8 * g) * 4u : OOB);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4] = {acc[c][4 * g], acc[c][4 * g + 1], acc[c][4 * g + 2], acc[c][4 * g + 3]};
+            const float bb[4] = {bias[g].x, bias[g].y, bias[g].z, bias[g].w};
+            const float m4[4] = {mk[g].x, mk[g].y, mk[g].z, mk[g].w};
+            const float x1[4] = {a1[g].x, a1[g].y, a1[g].z, a1[g].w};
+            const float x2[4] = {a2[g].x, a2[g].y, a2[g].z, a2[g].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] += bb[u];
+                if (e.add1) v[u] += x1[u];
+                if (e.add2) v[u] += x2[u];
+                if (e.lrelu) v[u] = fmaxf(v[u], leak * v[u]);
+                if (e.mask) v[u] *= m4[u] >= 0.f ? 1.f : LEAK;
+            }
+            if (rowok) *reinterpret_cast<float4*>(e.out1 + (int64_t)pix * e.ld1 + nn + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int HS, int WS, int PB>
+__global__ __launch_bounds__(WC_THREADS, 2) void wconvt_row_kernel(const WcT P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using G = WrGeo<WS, PB>;
+    // block -> (image group, grid row, column tile).  Blocks are dealt round-robin to the 8 XCDs; XCD x owns image groups x, x + 8, ...
+    // Order inside an XCD: ROW-major -- all interior rows (25 taps) of its groups first, then the last rows (20), then the first (15).
+    // A launch of these layers is about one round of resident blocks (two per CU), so its time is that of the slowest CU: with the
+    // long blocks dispatched first every CU gets a long one, and the short ones fill the second slots -- a (25, 15..20)-tap pair
+    // shares the matrix pipe instead of two 25-tap blocks on one CU and two short ones on another.  CTX_WCONVT_ROW_ORDER=1 (P.ksplit
+    // carries it) restores the group-major order (a group's rows adjacent in the XCD's L2).
+    const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int nig = (P.nimg + G::IMGT - 1) / G::IMGT, nigl = (nig + 7) / 8;
+    const int nt = l % P.gn, q = l / P.gn;
+    const int rsel = P.ksplit == 1 ? q / nigl : q % HS, ig = (P.ksplit == 1 ? q % nigl : q / HS) * 8 + xcd;
+    if (ig >= nig) return;
+    // interior rows first, the shorter border rows behind them
+    const int r = rsel < HS - 2 ? rsel + 1 : rsel == HS - 2 ? HS - 1 : 0;
+    const int img0 = ig * G::IMGT, n0 = nt * G::COLS;
+    if (r == 0) wr_body<HS, WS, 0, PB>(P, smem, img0, r, n0);
+    else if (r == HS - 1) wr_body<HS, WS, 2, PB>(P, smem, img0, r, n0);
+    else wr_body<HS, WS, 1, PB>(P, smem, img0, r, n0);
+}
+
+template <int HS, int WS, int PB>
+void launch_wr(hipStream_t s, WcT P) {
+    using G = WrGeo<WS, PB>;
+    static_assert(G::lds <= 80 * 1024, "two blocks per CU");
+    P.gn = P.ca / G::COLS;
+    const int nig = (P.nimg + G::IMGT - 1) / G::IMGT;
+    const int items = (nig + 7) / 8 * 8 * HS * P.gn;
+    ensure_dyn_lds((const void*)wconvt_row_kernel<HS, WS, PB>, G::lds);
+    hipLaunchKernelGGL((wconvt_row_kernel<HS, WS, PB>), dim3((unsigned)items), dim3(WC_THREADS), G::lds, s, P);
+}
+
 template <int HS, int WS, int NB>
 void launch_wc(hipStream_t s, const WcT& P) {
     constexpr int TH = HS * WS >= WC_ROWS ? WC_ROWS / WS : HS, IMGT = WC_ROWS / (TH * WS), TPI = HS / TH;
@@ -347,6 +599,23 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
     while (hs * ws <= ks_grid && ks < ks_max && ntile * (ca / (nb2 ? 64 : 32)) * ks < slots400 && nsl / (2 * ks) >= 4 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
     if (force_ks) ks = force_ks;
     if (ks == 1 && nb2 && !force_nb && ntile * (ca / 64) < slots400) nb2 = false;        // no room to split: narrower column tiles instead
+    // row blocks (above).  CTX_WCONVT_ROW: 0 = off (all-taps tiles everywhere), bit 1 = the 4x4 grids, bit 2 = the 8x8 grids;
+    // CTX_WCONVT_ROW_PB = 64 | 128 forces a tile shape on the 4x4 grids.
+    static const int rowk = [] { const char* e = getenv("CTX_WCONVT_ROW"); return e ? atoi(e) : 3; }();
+    static const int rowpb = [] { const char* e = getenv("CTX_WCONVT_ROW_PB"); return e ? atoi(e) : 0; }();
+    if (ks == 1 && !force_nb && ca % 64 == 0 && ((hs == 4 && (rowk & 1)) || (hs == 8 && (rowk & 2)))) {
+        static const bool gmajor = [] { const char* e = getenv("CTX_WCONVT_ROW_ORDER"); return e && e[0] == '1'; }();
+        P.ksplit = gmajor ? 2 : 1;                                 // (the row kernel does not split K: the field carries its block order)
+        P.slab = nullptr;
+        if (hs == 8) launch_wr<8, 8, 64>(s, P);
+        else {
+            // 128-position tiles (the filter traffic of the all-taps kernel) where they still make ~2 blocks per CU; else 64 x 64
+            const int64_t blocks128 = (int64_t)((nimg + 31) / 32) * 4 * (ca / 32);
+            const bool big = rowpb ? rowpb == 128 : blocks128 >= dev_info().cus * 2 * 3 / 4;
+            if (big) launch_wr<4, 4, 128>(s, P); else launch_wr<4, 4, 64>(s, P);
+        }
+        return;
+    }
     P.gn = nb2 ? ca / 64 : ca / 32;
     P.ksplit = ks;
     P.slab = ks > 1 ? wsp.slab : nullptr;
