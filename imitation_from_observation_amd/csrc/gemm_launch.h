@@ -1,7 +1,12 @@
 // gemm_launch.h -- tile-shape dispatch and split-K policy for igemm_kernel (included by gemm_*.hip)
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
+#include <string>
+#include <typeinfo>
 
 #include "launch.h"
 #include "igemm_split.h"
@@ -127,11 +132,26 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
+    {   // CTX_TRACE_LAUNCH=1: one stderr line per distinct launch shape (diagnostics)
+        static const bool trace = [] { const char* e = getenv("CTX_TRACE_LAUNCH"); return e && e[0] == '1'; }();
+        if (trace) {
+            static std::mutex mu;
+            static std::set<std::string> seen;
+            char buf[256];
+            snprintf(buf, sizeof buf, "igemm %s | M %d N %d nprob %d chunks %d..%d tile %dx%d tiles %lld nsplit %d swz %d/%d", __PRETTY_FUNCTION__ + 0 ? "" : "", M, N, nprob, min_chunks, max_chunks, 64 * MI, 64 * NI,
+                     (long long)tiles, nsplit, ep.xcd_swizzle, ep.swz_group);
+            std::lock_guard<std::mutex> g(mu);
+            if (seen.insert(std::string(buf) + typeid(LA).name()).second) fprintf(stderr, "%s  [%s x %s]\n", buf, typeid(LA).name(), typeid(LB).name());
+        }
+    }
     {   // problems of unequal length behind the XCD swizzle: balanced runs per XCD (launch.h: balanced_order).  The 8 XCDs share the
         // nsplit x nprob slots in order, so one split's problems are spread over 8 / nsplit of them.  CTX_BALANCE=0: plain order.
         if (prob_weight && ep.xcd_swizzle && !ep.swz_group && nprob >= 8) {
             const int nbins = nsplit <= 1 ? 8 : 8 % nsplit == 0 ? 8 / nsplit : 1;
-            ep.perm = balanced_order(prob_weight, nprob, nbins);
+            // (the heavy / light pairing distance only matters for a launch of about one round of resident blocks; a longer one gets
+            // the plain alternation, which keeps every window of the slot sequence near the mean)
+            const bool one_round = tiles * nsplit <= 3 * (int64_t)dev_info().cus;
+            ep.perm = balanced_order(prob_weight, nprob, nbins, one_round ? (int)(tiles / nprob) : 32);
         }
     }
     // narrow operands (ContextAEReal's 32-channel layers): tiles that do not multiply zeros.  f32 only.

@@ -43,9 +43,9 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
     }
 }
 
-int balance_bits() { static const int v = [] { const char* e = getenv("CTX_BALANCE"); return e ? atoi(e) : 1; }(); return v; }
+int balance_bits() { static const int v = [] { const char* e = getenv("CTX_BALANCE"); return e ? atoi(e) : 3; }(); return v; }
 
-const uint16_t* balanced_order(const int* weight, int nprob, int nbins) {
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem) {
     if (nprob <= 1 || nprob > 65535 || nbins < 1) return nullptr;
     static std::mutex mu;
     static std::map<std::pair<int, std::vector<int>>, uint16_t*> cache;
@@ -53,6 +53,7 @@ const uint16_t* balanced_order(const int* weight, int nprob, int nbins) {
     (void)hipGetDevice(&dev);
     std::vector<int> key(weight, weight + nprob);
     key.push_back(nbins);
+    key.push_back(tiles_per_problem);
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find({dev, key});
     if (it != cache.end()) return it->second;
@@ -70,21 +71,27 @@ const uint16_t* balanced_order(const int* weight, int nprob, int nbins) {
         bins[best].push_back(p);
         sum[best] += weight[p];
     }
-    // inside a run: heaviest, lightest, second heaviest, second lightest, ... (each bin is sorted heavy -> light by construction)
+    // Inside a run.  An XCD hands its run's blocks to its 32 CUs in order, so blocks l and l + 32 of the run share a CU (two resident
+    // blocks per CU): with T tiles per problem these are problem slots i and i + d, d = 32 / T (T <= 32).  Slots are filled in groups of
+    // 2 d: the d heaviest problems left, then the d lightest in reverse order -- every CU pairs a heavy block with a light one.
+    // (each bin is sorted heavy -> light by construction)
+    const int d = tiles_per_problem >= 32 ? 1 : tiles_per_problem > 0 ? 32 / tiles_per_problem : 1;
     std::vector<uint16_t> order;
     order.reserve(nprob);
     for (int b = 0; b < nbins; ++b) {
         int lo = 0, hi = (int)bins[b].size() - 1;
         while (lo <= hi) {
-            order.push_back((uint16_t)bins[b][lo++]);
-            if (lo <= hi) order.push_back((uint16_t)bins[b][hi--]);
+            const int left = hi - lo + 1, nh = left >= 2 * d ? d : (left + 1) / 2, nl = left >= 2 * d ? d : left - nh;
+            for (int k = 0; k < nh; ++k) order.push_back((uint16_t)bins[b][lo + k]);
+            for (int k = 0; k < nl; ++k) order.push_back((uint16_t)bins[b][hi - k]);
+            lo += nh; hi -= nl;
         }
     }
-    uint16_t* d = nullptr;
-    if (hipMalloc((void**)&d, nprob * sizeof(uint16_t)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d, order.data(), nprob * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
-    cache[{dev, key}] = d;
-    return d;
+    uint16_t* dptr = nullptr;
+    if (hipMalloc((void**)&dptr, nprob * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dptr, order.data(), nprob * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dptr); return nullptr; }
+    cache[{dev, key}] = dptr;
+    return dptr;
 }
 
 namespace { thread_local char g_launch_err[256]; thread_local bool g_launch_err_set = false; }

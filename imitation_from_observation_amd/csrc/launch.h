@@ -23,14 +23,15 @@ void ensure_dyn_lds(const void* kernel, size_t bytes);
 // a 4x4 grid; rectangle-ordered filter gradients: 9/16 .. 16/16 of the positions per tap).  With the XCD swizzle an XCD runs a
 // CONTIGUOUS run of problem slots and a launch of about one round of resident blocks ends with its slowest XCD: in row-major order
 // the 4x4 conv's XCDs get 24 .. 45 taps (mean 36), i.e. the launch runs at 80 %.  balanced_order deals the problems to `nbins` runs
-// of (nearly) equal length by longest-first greedy, heavy and light alternating inside a run (the two blocks that share a CU come
-// from different parts of the run), and returns the order as a DEVICE array of nprob uint16 (cached per weight vector and device;
+// of (nearly) equal length by longest-first greedy, heavy and light problems placed inside a run so that the two blocks that share
+// a CU (blocks l and l + 32 of an XCD's run) are a heavy and a light one, and returns the order as a DEVICE array of nprob uint16 (cached per weight vector and device;
 // created on first use -- a synchronous 2 * nprob-byte copy).  Same problems, same arithmetic per problem: results do not change.
-const uint16_t* balanced_order(const int* weight, int nprob, int nbins);
-// CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (default: the
-// 4x4 layers, two positions per XCD -- d_h1's input gradient 0.675 -> 0.587 ms); 2 = on larger grids too (8x8: a contiguous run of
-// positions is a grid row whose blocks share input pixels in the XCD's L2 -- scattering them cost more than the 7.5 % imbalance);
-// 4 = the rectangle-ordered filter gradient's 25 taps.
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem);
+// CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (the 4x4
+// layers: d_h1's input gradient 0.675 -> 0.59 ms, h3_conv forward 0.352 -> 0.316); 2 = on larger grids too (with the pair-aware order
+// inside a run: -0.03 ms of step; before it the scattered positions of an 8x8 grid cost more L2 misses than the 7.5 % imbalance);
+// 4 = the rectangle-ordered filter gradient's 25 taps (+0.05 ms of step: its launches run several rounds and balance themselves).
+// Default 3.
 int balance_bits();
 
 // Split-K policy shared by all launchers: `slab` is scratch of `slab_floats` floats.

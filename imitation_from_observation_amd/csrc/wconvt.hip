@@ -357,8 +357,13 @@ __device__ __forceinline__ void wr_lane_pos(int wv, int row, int& il, int& pj) {
     else il = (wv & 1) * (32 / WS) + (k / WS) * 2 + (ga ? 0 : 1);
 }
 
-template <int HS, int WS, int RT, int PB>
-__device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int r, int n0) {
+// XS (PB = 128 only): the x direction too.  Wave w owns ONE COLUMN of the row -- the 32 images' position (r, (w + rot) & 3) -- so every
+// MFMA's 32 columns are one grid position and a tap that reads column -1 or WS is skipped by that wave (a scalar branch): the exact
+// (5 n - 3)^2 / (5 n)^2 of the products.  The waves of a block then carry 3/5, 1, 1, 4/5 of the x taps; they meet at the filter ring's
+// barrier every tap, so the skipped time only counts if another wave uses the SIMD: the launcher hands `rot` = 0 | 2 to the two
+// blocks that share a CU (blocks l and l + 32 of an XCD's run), whose waves on one SIMD are then columns (0, 2) / (1, 3) / (2, 0) / (3, 1).
+template <int HS, int WS, int RT, int PB, bool XS = false>
+__device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int r, int n0, int rot = 0) {
     using G = WrGeo<WS, PB>;
     constexpr int IMGT = G::IMGT, HP = G::HP, WPL = G::WPL, TPIX = G::TPIX, LEAD = G::LEAD, COLS = G::COLS;
     constexpr int NPA = (TPIX * 8 + WC_THREADS - 1) / WC_THREADS;
@@ -411,7 +416,8 @@ __device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int
     // the lane's position (image il of the tile, column pj of grid row r); base = the slot of input pixel (r - 1, pj - 1), so that tap
     // (dy, dx) is the literal offset ((dy + 1) WPL + dx + 1) slots
     int il, pj;
-    wr_lane_pos<WS, PB>(wv, l31, il, pj);
+    if constexpr (XS) { il = l31; pj = (__builtin_amdgcn_readfirstlane(wv) + rot) & (WS - 1); }      // (pj in a scalar register: uniform branches below)
+    else wr_lane_pos<WS, PB>(wv, l31, il, pj);
     const float* aBase = sA + (LEAD + il * HP * WPL + pj - (G::PACK ? 1 : 0)) * WC_LDP + 4 * h;
     const float* bBase = sB + (32 * wc + l31) * WC_LDP + 4 * h;
 
@@ -439,19 +445,25 @@ __device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int
             const int stage = (s * NT + n) & 1;
             const float* aT = aBase + ((ti.dy + 1) * WPL + (ti.dx + 1)) * WC_LDP;
             const float* bT = bBase + stage * BSTAGE;
+            // XS: this wave's column has no pixel under the tap
+            const bool live = !XS || !((ti.dx < 0 && pj == 0) || (ti.dx > 0 && pj == WS - 1));
             float4 a[2], b[2];
-            a[0] = *reinterpret_cast<const float4*>(aT);
-            b[0] = *reinterpret_cast<const float4*>(bT);
+            if (live) {
+                a[0] = *reinterpret_cast<const float4*>(aT);
+                b[0] = *reinterpret_cast<const float4*>(bT);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q < 3) {
-                    a[(q + 1) & 1] = *reinterpret_cast<const float4*>(aT + 8 * (q + 1));
-                    b[(q + 1) & 1] = *reinterpret_cast<const float4*>(bT + 8 * (q + 1));
-                }
-                const float av[4] = {a[q & 1].x, a[q & 1].y, a[q & 1].z, a[q & 1].w};
-                const float bv[4] = {b[q & 1].x, b[q & 1].y, b[q & 1].z, b[q & 1].w};
+                if (live) {
+                    if (q < 3) {
+                        a[(q + 1) & 1] = *reinterpret_cast<const float4*>(aT + 8 * (q + 1));
+                        b[(q + 1) & 1] = *reinterpret_cast<const float4*>(bT + 8 * (q + 1));
+                    }
+                    const float av[4] = {a[q & 1].x, a[q & 1].y, a[q & 1].z, a[q & 1].w};
+                    const float bv[4] = {b[q & 1].x, b[q & 1].y, b[q & 1].z, b[q & 1].w};
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) acc[ti.cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tt], av[tt], acc[ti.cls], 0, 0, 0);
+                    for (int tt = 0; tt < 4; ++tt) acc[ti.cls] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tt], av[tt], acc[ti.cls], 0, 0, 0);
+                }
                 if (q == 0) b_store(stage ^ 1, breg);
                 if (q == 1) {
                     const TapInfo tj = tap_info(wr_tap(RT, n + 2));
@@ -517,7 +529,7 @@ __device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int
     }
 }
 
-template <int HS, int WS, int PB>
+template <int HS, int WS, int PB, bool XS = false>
 __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_row_kernel(const WcT P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using G = WrGeo<WS, PB>;
@@ -535,20 +547,21 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_row_kernel(const WcT P) 
     // interior rows first, the shorter border rows behind them
     const int r = rsel < HS - 2 ? rsel + 1 : rsel == HS - 2 ? HS - 1 : 0;
     const int img0 = ig * G::IMGT, n0 = nt * G::COLS;
-    if (r == 0) wr_body<HS, WS, 0, PB>(P, smem, img0, r, n0);
-    else if (r == HS - 1) wr_body<HS, WS, 2, PB>(P, smem, img0, r, n0);
-    else wr_body<HS, WS, 1, PB>(P, smem, img0, r, n0);
+    const int rot = XS ? ((l >> 5) & 1) * (WS / 2) : 0;       // blocks l and l + 32 of an XCD's run share a CU: complementary columns per SIMD
+    if (r == 0) wr_body<HS, WS, 0, PB, XS>(P, smem, img0, r, n0, rot);
+    else if (r == HS - 1) wr_body<HS, WS, 2, PB, XS>(P, smem, img0, r, n0, rot);
+    else wr_body<HS, WS, 1, PB, XS>(P, smem, img0, r, n0, rot);
 }
 
-template <int HS, int WS, int PB>
+template <int HS, int WS, int PB, bool XS = false>
 void launch_wr(hipStream_t s, WcT P) {
     using G = WrGeo<WS, PB>;
     static_assert(G::lds <= 80 * 1024, "two blocks per CU");
     P.gn = P.ca / G::COLS;
     const int nig = (P.nimg + G::IMGT - 1) / G::IMGT;
     const int items = (nig + 7) / 8 * 8 * HS * P.gn;
-    ensure_dyn_lds((const void*)wconvt_row_kernel<HS, WS, PB>, G::lds);
-    hipLaunchKernelGGL((wconvt_row_kernel<HS, WS, PB>), dim3((unsigned)items), dim3(WC_THREADS), G::lds, s, P);
+    ensure_dyn_lds((const void*)wconvt_row_kernel<HS, WS, PB, XS>, G::lds);
+    hipLaunchKernelGGL((wconvt_row_kernel<HS, WS, PB, XS>), dim3((unsigned)items), dim3(WC_THREADS), G::lds, s, P);
 }
 
 template <int HS, int WS, int NB>
@@ -612,7 +625,8 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
             // 128-position tiles (the filter traffic of the all-taps kernel) where they still make ~2 blocks per CU; else 64 x 64
             const int64_t blocks128 = (int64_t)((nimg + 31) / 32) * 4 * (ca / 32);
             const bool big = rowpb ? rowpb == 128 : blocks128 >= dev_info().cus * 2 * 3 / 4;
-            if (big) launch_wr<4, 4, 128>(s, P); else launch_wr<4, 4, 64>(s, P);
+            static const bool xs = [] { const char* e = getenv("CTX_WCONVT_XS"); return !(e && e[0] == '0'); }();      // column-uniform waves (x taps skipped too)
+            if (big && xs) launch_wr<4, 4, 128, true>(s, P); else if (big) launch_wr<4, 4, 128>(s, P); else launch_wr<4, 4, 64>(s, P);
         }
         return;
     }
