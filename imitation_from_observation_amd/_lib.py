@@ -105,6 +105,10 @@ SIGNATURES = {
     "ctx_sync": (_c.c_int, [_P]),
     "ctx_dev_outputs": (_c.c_int, [_P, _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P), _c.POINTER(_P)]),
     "ctx_last_codes": (_c.c_int, [_P, _F, _F, _c.POINTER(_c.c_int)]),
+    "ctx_option_count": (_c.c_int, []),
+    "ctx_option_name": (_c.c_char_p, [_c.c_int]),
+    "ctx_get_option": (_c.c_int, [_P, _c.c_char_p, _c.POINTER(_c.c_int)]),
+    "ctx_set_option": (_c.c_int, [_P, _c.c_char_p, _c.c_int]),
     "ctx_dp_unique_id": (_c.c_int, [_U8]),
     "ctx_dp_init": (_c.c_int, [_P, _U8, _c.c_int, _c.c_int]),
     "ctx_dp_world": (_c.c_int, [_P, _c.POINTER(_c.c_int), _c.POINTER(_c.c_int)]),

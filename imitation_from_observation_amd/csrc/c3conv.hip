@@ -245,8 +245,7 @@ void launch_c3_w(hipStream_t s, const C3P& P) {
 
 // the shapes this kernel is instantiated for
 bool c3conv_ok(int hin, int win, int stride, int N, const Epi& ep) {
-    static const bool on = [] { const char* e = getenv("CTX_C3CONV"); return !(e && e[0] == '0'); }();
-    if (!on || (stride != 1 && stride != 2) || hin % stride || win % stride) return false;
+    if (!(opt(OPT_DIRECT3) & 2) || (stride != 1 && stride != 2) || hin % stride || win % stride) return false;
     if (N != 32 && N != 64 && N != 128) return false;
     if ((win / stride) % 16) return false;                               // whole 16-pixel row blocks
     if (ep.add1 || ep.add2 || ep.slab || ep.rowmode) return false;

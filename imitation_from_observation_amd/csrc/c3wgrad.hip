@@ -224,8 +224,7 @@ void launch_w3(hipStream_t s, W3P P, int ngroups) {
 }  // namespace
 
 bool c3wgrad_ok(const DcWgrad& P) {
-    static const bool on = [] { const char* e = getenv("CTX_C3WGRAD"); return !(e && e[0] == '0'); }();
-    if (!on || P.CA != 3 || P.ldb != 3 || (P.S != 1 && P.S != 2) || P.pad != (P.S == 2 ? 1 : 2)) return false;
+    if (!(opt(OPT_DIRECT3) & 4) || P.CA != 3 || P.ldb != 3 || (P.S != 1 && P.S != 2) || P.pad != (P.S == 2 ? 1 : 2)) return false;
     if (P.hb != P.S * P.hs || P.wb != P.S * P.ws) return false;
     if (P.ws % 16 || P.hs % (P.ws % 32 == 0 ? 4 : 8)) return false;                      // whole 128-pixel tiles
     const int NP = P.CB >= 64 ? 64 : 32;

@@ -25,6 +25,7 @@
 using namespace ctx;
 
 struct ctx_cnn {
+    Options opt{};                                    // this handle's switches (options.h): the environment's at ctx_cnn_create
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -83,7 +84,7 @@ int same_before(int n, int k, int s) {
 // Buffer 0 holds 3 real channels.  When every reader is a square 3x3 / 5x5 conv it is stored 4 channels wide and those
 // convs run on the cin = 3 gather (K = 4 x taps instead of 32 x taps: Conv2d_1a_3x3 0.245 -> 0.05 ms at 192 x 125 x 125).
 bool stem4_ok(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>& ops) {
-    static const bool on = [] { const char* e = getenv("CTX_CNN_STEM4"); return !(e && e[0] == '0'); }();
+    const bool on = opt(OPT_CNN_STEM4) != 0;
     bool any = false;
     for (const ctx_cnn_op& op : ops) {
         if (op.dst == 0) return false;
@@ -141,6 +142,7 @@ int validate(const std::vector<ctx_cnn_buf>& bufs, const std::vector<ctx_cnn_op>
 // GEMMs that do not fill the chip alone); each op is ordered after the ops that wrote its src buffer, and the pass ends
 // with every lane joined into lane 0.  With `ev` (profiling) everything runs on lane 0, one event per op boundary.
 int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
+    OptScope os(&h->opt);
     const bool par = h->overlap && !ev;
     if (par) {
         (void)hipEventRecord(h->ev_fork, h->lane[0]);
@@ -194,7 +196,7 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
 // The ~107 launches of a pass are 20-120 us each: captured into a hipGraph on the second pass with a given image count and
 // replayed afterwards (a kernel trace of the config-4 step showed the device idle ~9 % of the time between them).  Single-lane
 // passes only (the branch lanes of the split-bf16 mode keep plain launches); every pointer a launch captures is owned by the
-// handle.  CTX_GRAPHS=0 keeps plain launches.
+// handle.  Option "graphs" = 0 (CTX_GRAPHS=0 in the environment at create) keeps plain launches.
 int run_cached(ctx_cnn* h, int n) {
     if (!h->use_graphs || h->overlap) return run(h, n);
     ctx_cnn::GraphSlot& g = h->graphs[n];
@@ -238,6 +240,8 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     if (device < 0 || device >= ndev) return cfail(nullptr, CTX_E_INVALID, "device %d out of range", device);
     if (hipSetDevice(device) != hipSuccess) return cfail(nullptr, CTX_E_DEVICE, "hipSetDevice failed");
     ctx_cnn* h = new ctx_cnn();
+    h->opt = options_from_env();
+    OptScope os(&h->opt);
     h->device = device; h->max_images = max_images; h->precision = precision; h->bufs = vb; h->ops = vo; h->weight_floats = weight_floats;
     bool ok = true;
     if (stream) h->stream = (hipStream_t)stream;
@@ -268,8 +272,8 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     }
     if (ok) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     // measured at 192 images of 125x125: branch lanes -11 % in the split-bf16 mode, +2 % (and a slower chained train step) in f32
-    { const char* e = getenv("CTX_CNN_LANES"); h->overlap = e ? e[0] != '0' : precision == CTX_PREC_BF16X3; }
-    { const char* e = getenv("CTX_GRAPHS"); h->use_graphs = !(e && e[0] == '0'); }
+    h->overlap = h->opt.v[OPT_CNN_LANES] < 0 ? precision == CTX_PREC_BF16X3 : h->opt.v[OPT_CNN_LANES] != 0;
+    h->use_graphs = h->opt.v[OPT_GRAPHS] != 0;
     alloc((void**)&h->zeros, 256, true);
     if (!ok) { cfail(nullptr, CTX_E_NOMEM, "device allocation failed"); ctx_cnn_destroy(h); return CTX_E_NOMEM; }
     *out = h;

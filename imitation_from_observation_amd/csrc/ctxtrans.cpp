@@ -53,6 +53,7 @@ namespace { struct GenState; }
 
 struct ctx_handle {
     ctx_config cfg{};
+    Options opt{};               // this handle's switches (options.h; ctx_set_option): the process defaults (environment) at ctx_create
     GenState* gen = nullptr;     // CTX_VARIANT_REAL / CTX_VARIANT_INCEPTION2 state (ctxtrans_gen.inc)
     int Fp = 0;                  // row stride of the code buffers Z / dZ (featsize, or featsize padded to 32 for REAL)
     int device = 0;
@@ -121,6 +122,8 @@ struct ctx_handle {
     hipStream_t dp_stream = nullptr;
     hipEvent_t dp_ev_ready = nullptr, dp_ev_done = nullptr;
     float* dp_scal = nullptr;
+    double* dp_host_buf = nullptr;    // device staging of ctx_dp_allreduce_host_f64, grown on demand (not per call)
+    size_t dp_host_cap = 0;
     bool dp_in_step = false;      // inside ctx_dp_train_step: fire_bucket starts the tail bucket's all-reduce itself
     int64_t dp_split = -1;        // first float of the tail bucket once it has been started in this step
     int dp_rc = 0;                // result of the collectives started from inside backward
@@ -464,14 +467,13 @@ constexpr int LANE_CTX = 0, LANE_DW = 1;
 // MEASURED (round 3, six back-to-back bench runs): no gain -- 13.79 / 13.81 ms with the slices against 13.79 / 13.79 without, tail
 // slice only 13.76, encoder slices only 13.83.  The matrix-core kernels it would hide under own the CUs' registers and LDS, so the
 // Adam blocks displace their blocks instead of running beside them: the step costs the sum of the work either way.  OFF unless
-// CTX_EARLY_ADAM=1 (read at every step, so a test can switch it).
+// option "early_adam" is set (ctx_set_option; read at every step).
 void adam_launch(ctx_handle* h, hipStream_t s, int64_t first, int64_t end) {
     adam(s, h->arena + first, h->arena + h->Ppad + first, h->arena + 2 * h->Ppad + first, h->arena + 3 * h->Ppad + first, end - first,
          h->adam_lr_t, 0.9f, 0.999f, 1e-8f);
 }
 void adam_begin(ctx_handle* h, float lr) {
-    const char* ev = getenv("CTX_EARLY_ADAM");
-    const bool env_on = ev && ev[0] == '1';
+    const bool env_on = h->opt.v[OPT_EARLY_ADAM] != 0;
     const double b1 = 0.9, b2 = 0.999;
     h->adam_t += 1;
     h->adam_lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t)));
@@ -581,7 +583,7 @@ KmPlain km(const float* p, int64_t ld, int R, int K) { return KmPlain{p, ld, nul
 // columns, so a handle with df_dim > 64 stays on the implicit GEMM for all of its 3-channel layers (decided per handle, because
 // the implicit GEMM needs the 4-channel copies refreshed by forward / backward).
 bool use_dc3(const ctx_handle* h) {
-    static const bool on = [] { const char* e = getenv("CTX_DCONV_C3"); return !(e && e[0] == '0'); }();
+    const bool on = (h->opt.v[OPT_DIRECT3] & 1) != 0;
     // (both precisions: the seven 3-channel launches are 1 % of the step's FLOPs, and their exact-f32 direct kernels are faster than the
     // split-bf16 implicit GEMM on 4-channel copies -- 0.8 ms against 1.5 ms of the split-bf16 step -- and more accurate)
     return on && dconv_ok(3, h->d) && dconv_ok(3, 2 * h->d);
@@ -591,12 +593,14 @@ bool use_dc3(const ctx_handle* h) {
 // ContextSkipNew: both precisions (exact f32 arithmetic either way); the table-driven models: exact-f32 mode only.
 // CTX_CONVT3_DIRECT=0 restores the two-step route (and its P3 buffer).
 bool d_h4_direct(const ctx_handle* h, int c1, int c2, int hs, int ws, int stride) {
-    static const bool on = [] { const char* e = getenv("CTX_CONVT3_DIRECT"); return !(e && e[0] == '0'); }();
+    const bool on = (h->opt.v[OPT_DIRECT3] & 8) != 0;
     return on && (h->cfg.precision == CTX_PREC_F32 || !h->gen) && convt3_direct_ok(c1, c2, hs, ws, stride);
 }
-bool use_q(int nimg) { static const bool on = [] { const char* e = getenv("CTX_POSMAJOR"); return !(e && e[0] == '0'); }(); return on && nimg >= 64; }
+bool use_q(int nimg) { return opt(OPT_POSMAJOR) && nimg >= 64; }
 
-int q_minpos(const ctx_handle* h) { static const int v = [] { const char* e = getenv("CTX_Q_MINPOS"); return e ? atoi(e) : -1; }(); return v >= 0 ? v : (h->cfg.precision ? 0 : 64); }
+// smallest grid (positions) whose transposed conv runs position-major: in f32 the 4x4 grids keep the class-major launch (64 problems of
+// 1 .. 9 taps leave a tail)
+int q_minpos(const ctx_handle* h) { return h->cfg.precision ? 0 : 64; }
 
 // y = lrelu(conv2d(x) + b): x [nimg, hb, wb, ca] -> y [nimg, hb/2, wb/2, cb]
 void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg, int hb, int wb, int ca, const float* w,
@@ -696,6 +700,7 @@ namespace {
 // TRANSLATE: only what translated_z / out depend on (src encoder, ctx encoder, translate, decoder
 // pass 1) -- the subgraph TF would run for base.py:216-218.  ENCODE: `conv` encoder on src only.
 void forward(ctx_handle* h, int B, Mode mode) {
+    OptScope os(&h->opt);
     if (h->gen) { gen_forward(h, B, mode); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
@@ -736,7 +741,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
         const double fl = 2.0 * nd * hs * ws * 25 * (c1 + c2) * ca, uf = tap_frac(2 * hs, 2 * ws, 5, 2);
         if (k < 4) {
             const int R = nd * hs * ws;
-            const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, ws, c1, c2, ca);
+            const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, ws, c1, c2, ca, nd);
             ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl, uf);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
@@ -764,6 +769,7 @@ void forward(ctx_handle* h, int B, Mode mode) {
 // d loss / d params into the grad arena (what AdamOptimizer.minimize differentiates,
 // scripts/train_script.py:128).  Every gradient tensor is written exactly once.
 void backward(ctx_handle* h, int B, int sim_batch) {
+    OptScope os(&h->opt);
     if (h->gen) { gen_backward(h, B, sim_batch); return; }
     g_zeros = h->zeros;
     const int d = h->d, F = h->F;
@@ -920,7 +926,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                 ed.add2 = h->dSk[k - 1] + (int64_t)B * hb * wb * ca; ed.lda2 = ca;
             }
             // (split-bf16 mode: the exact-f32 kernel only where it is the faster one -- the 16x16 grids' few-channel input gradients)
-            const bool wide = (h->cfg.precision == CTX_PREC_F32 || hs == 16) && wconvt_ok(hs, wsm, cb, 0, ca);
+            const bool wide = (h->cfg.precision == CTX_PREC_F32 || hs == 16) && wconvt_ok(hs, wsm, cb, 0, ca, nimg);
             ProfScope ps(h, ln + " dx", wide ? K_WCONVT : K_CONVT, fl, uf);
             if (wide) wconvt_fwd(h->stream, dA[k], cb, nullptr, 0, 1, nimg, hs, wsm, sc.w[k], ca, ed, ws_of(h));
             else if (use_q(nimg) && hs * wsm >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dA[k], cb, cb, nullptr, 0, 1, make_tposgeo(hs, wsm, 5, 1, cb / KC), nimg, g_zeros},
@@ -1157,6 +1163,8 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     if (e != hipSuccess) return fail(nullptr, CTX_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
     ctx_handle* h = new ctx_handle();
     h->cfg = *cfg;
+    h->opt = options_from_env();             // CTX_<NAME> in the environment = this handle's defaults; ctx_set_option changes them
+    OptScope os(&h->opt);
     h->device = device;
     h->H = cfg->H; h->W = cfg->W; h->d = cfg->df_dim; h->F = cfg->featsize; h->Bm = cfg->max_batch;
     for (int k = 0; k < 5; ++k) { h->hh[k] = cfg->H >> k; h->ww[k] = cfg->W >> k; }
@@ -1189,17 +1197,11 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     }
     if (rc == CTX_OK) rc = h->gen ? gen_alloc(h) : alloc_buffers(h);
     if (rc == CTX_OK) {
-        const char* ov = getenv("CTX_OVERLAP");
-        h->overlap = !(ov && ov[0] == '0');
-        const char* gr = getenv("CTX_GRAPHS");
-        h->use_graphs = !(gr && gr[0] == '0');
-        // Side-lane stream priority.  Lowest (CTX_LANE_PRIO=1) is -0.03 ms on the ContextSkipNew step and -0.7 ms on the
-        // split-bf16 config-4 step, but the f32 config-4 step (front end chained on the same stream) went from 7.8 to 17.4 ms
-        // with it: the default stays NORMAL.  2 = highest (+0.08 ms).
-        const char* lp = getenv("CTX_LANE_PRIO");
-        int prio_low = 0, prio_high = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-        const int lane_prio = (lp && lp[0] == '1') ? prio_low : (lp && lp[0] == '2') ? prio_high : 0;
+        h->overlap = h->opt.v[OPT_OVERLAP] != 0;
+        h->use_graphs = h->opt.v[OPT_GRAPHS] != 0;
+        // Side-lane stream priority: NORMAL.  (Lowest was -0.03 ms on the ContextSkipNew step and -0.7 ms on the split-bf16 config-4
+        // step, but the f32 config-4 step -- front end chained on the same stream -- went from 7.8 to 17.4 ms with it; highest +0.08 ms.)
+        const int lane_prio = 0;
         for (int l = 0; l < ctx_handle::NLANE && rc == CTX_OK; ++l)
             if (hipStreamCreateWithPriority(&h->aux[l], hipStreamNonBlocking, lane_prio) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming) != hipSuccess ||
@@ -1236,6 +1238,7 @@ void ctx_destroy(ctx_handle* h) {
     for (auto& rc : h->rcache) { if (rc.means) (void)hipFree(rc.means); if (rc.imgs) (void)hipFree(rc.imgs); }
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->vdata) (void)hipFree(h->vdata);
+    if (h->dp_host_buf) (void)hipFree(h->dp_host_buf);
     for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     delete h->gen;
     dp_teardown(h);
@@ -1670,6 +1673,37 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
     return CTX_OK;
 }
 
+// ---- per-handle options (csrc/options.h) ---------------------------------------------------------------------------------------
+int ctx_option_count(void) { return OPT_COUNT; }
+const char* ctx_option_name(int index) { return opt_name(index); }
+int ctx_get_option(const ctx_handle* h, const char* name, int* value) {
+    if (!h || !value) return CTX_E_INVALID;
+    const int i = opt_find(name);
+    if (i < 0) return CTX_E_INVALID;
+    *value = h->opt.v[i];
+    return CTX_OK;
+}
+int ctx_set_option(ctx_handle* h, const char* name, int value) {
+    if (!h) return CTX_E_INVALID;
+    const int i = opt_find(name);
+    if (i < 0) return fail(h, CTX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
+    // options that decided the handle's buffers or kernels' parameter layouts at ctx_create cannot change afterwards
+    if ((i == OPT_DIRECT3 || i == OPT_DCONV) && value != h->opt.v[i])
+        return fail(h, CTX_E_STATE, "option '%s' is fixed at ctx_create (it decides buffers and layouts): set CTX_%s in the environment before creating the handle", opt_name(i), "<NAME>");
+    h->opt.v[i] = value;
+    if (i == OPT_OVERLAP) h->overlap = value != 0;
+    if (i == OPT_GRAPHS) {
+        h->use_graphs = value != 0;
+        for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        h->graphs.clear();
+    }
+    if (i != OPT_TRACE_LAUNCH && i != OPT_EARLY_ADAM) {      // anything that changes which kernels a captured forward holds
+        for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        h->graphs.clear();
+    }
+    return CTX_OK;
+}
+
 int ctx_dp_unique_id(uint8_t id[CTX_DP_UNIQUE_ID_BYTES]) {
     if (!id) return fail(nullptr, CTX_E_INVALID, "id is NULL");
     if (!rccl_load()) return fail(nullptr, CTX_E_DEVICE, "librccl could not be loaded: %s", rccl().err.c_str());
@@ -1825,8 +1859,12 @@ int ctx_dp_allreduce_host_f64(ctx_handle* h, double* buf, size_t n) {
     if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
     if (n == 0) return CTX_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    double* d = nullptr;                                   // (a cache-build call, a few MB once per rollout batch: allocated per call)
-    if (hipMalloc((void**)&d, n * sizeof(double)) != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%zu bytes) for the host all-reduce", n * sizeof(double));
+    if (n > h->dp_host_cap) {                               // staging buffer owned by the handle, grown when a larger call arrives
+        if (h->dp_host_buf) { (void)hipFree(h->dp_host_buf); h->dp_host_buf = nullptr; h->dp_host_cap = 0; }
+        if (hipMalloc((void**)&h->dp_host_buf, n * sizeof(double)) != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%zu bytes) for the host all-reduce", n * sizeof(double));
+        h->dp_host_cap = n;
+    }
+    double* d = h->dp_host_buf;
     int rc = CTX_OK;
     do {
         if (hipMemcpyAsync(d, buf, n * sizeof(double), hipMemcpyHostToDevice, h->dp_stream) != hipSuccess) { rc = fail(h, CTX_E_DEVICE, "host all-reduce: upload failed"); break; }
@@ -1835,7 +1873,6 @@ int ctx_dp_allreduce_host_f64(ctx_handle* h, double* buf, size_t n) {
         if (hipMemcpyAsync(buf, d, n * sizeof(double), hipMemcpyDeviceToHost, h->dp_stream) != hipSuccess) { rc = fail(h, CTX_E_DEVICE, "host all-reduce: download failed"); break; }
     } while (0);
     const hipError_t es = hipStreamSynchronize(h->dp_stream);
-    (void)hipFree(d);
     if (rc == CTX_OK && es != hipSuccess) rc = fail(h, CTX_E_DEVICE, "host all-reduce: %s", hipGetErrorString(es));
     return rc;
 }

@@ -52,7 +52,7 @@ void launch_fwd_mi(hipStream_t s, const DcFwd& P, int MI, int NB, int occ, dim3 
 
 // measurement hook (tools/dconv_bench.hip): force the tile of the next launches; 0 = automatic
 int g_dc_force[3] = {0, 0, 0};       // TH, TW, MI
-int g_dc_occ = [] { const char* e = getenv("CTX_DCONV_OCC"); return e ? atoi(e) : 0; }();   // 1: never two blocks per CU (A/B)
+int g_dc_occ = 0;   // 1: never two blocks per CU (the round-2 A/B switch: two blocks are +8 % on the h2 / h3 / d_h1 layers)
 void dconv_force_tile(int th, int tw, int mi) { g_dc_force[0] = th; g_dc_force[1] = tw; g_dc_force[2] = mi; }
 int g_dc_last[4] = {0, 0, 0, 0};     // TH, TW, MI, GT of the last forward launch
 

@@ -10,7 +10,7 @@ namespace ctx {
 // share one L2.  Measured fetch bytes per launch at unchanged time: conv 652 -> 416 MB, filter gradient 1354 -> 606 MB,
 // transposed conv 851 -> 699 MB.  The transposed conv is swizzled PER PARITY CLASS (Epi::swz_group): its classes differ in
 // length, and one contiguous run per XCD over the whole launch (= one class per XCD) cost 20 % time.
-int xcd_swz() { static const int v = [] { const char* e = getenv("CTX_XCD_SWIZZLE"); return e ? atoi(e) : 7; }(); return v; }
+int xcd_swz() { return opt(OPT_XCD_SWIZZLE); }
 void conv_fwd(hipStream_t s, const KmConvGather& a, const NmPlain& b_, Epi ep, int M, int N, SplitWs ws) {
     NmPlain b = b_;
     b.seglen = a.tap_outer ? 0 : a.cps * KC;     // filter rows in KmConvGather's K order (A/B measured: no difference)

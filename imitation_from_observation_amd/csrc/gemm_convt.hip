@@ -8,8 +8,7 @@ void convt_fwd(hipStream_t s, const KmConvTGather& a, const KmConvTWeights& b, E
     // the four parity classes have different K extents (4/6/6/9 taps for k 5); each class is split into the same number of
     // parts, and the cost model sees the shortest class (small grids -- the 4x4 and 8x8 layers -- do not fill the chip otherwise)
     const int par = a.pb & 1, tmin = ((a.K - (1 - par) + 1) / 2) * ((a.K - (1 - par) + 1) / 2);
-    static const bool sk = [] { const char* e = getenv("CTX_CONVT_SPLITK"); return !(e && e[0] == '0'); }();
-    launch_igemm<KmConvTGather, KmConvTWeights, true, 2, 2>(s, a, b, ep, M, N, 4, sk ? tmin * a.cps : 0, ws);
+    launch_igemm<KmConvTGather, KmConvTWeights, true, 2, 2>(s, a, b, ep, M, N, 4, tmin * a.cps, ws);
 }
 void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& b, Epi ep, int N, SplitWs ws) {
     ep.rowmode = 5; ep.hs = a.g.hs; ep.ws = a.g.ws; ep.xcd_swizzle = ((xcd_swz() & ws.swz) >> 1) & 1; ep.swz_group = 1;   // grouped by parity class (set to the group size by the launcher)

@@ -78,11 +78,10 @@ static void launch_128(hipStream_t s, const LA& a, const LB& b, const Epi& ep, i
 template <class LA, class LB, bool BIG = false, int W32 = 1, int WSP = 0>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
                          SplitWs ws, int max_chunks = 0, const int* prob_weight = nullptr) {
-    static const int force = [] { const char* e = getenv("CTX_TILE"); return e ? atoi(e) : 0; }();   // 1: never big, 2: big when legal
     if constexpr (BIG) {
         const int64_t big_tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256) * nprob;
         // (since the 128x128 tile runs eight waves the 256x256 tile only pays in the split-bf16 mode: f32 conv gather -2.4 % without it)
-        if (force != 1 && M >= 256 && N >= 256 && ((big_tiles >= 192 && ws.prec) || force == 2)) {
+        if (M >= 256 && N >= 256 && big_tiles >= 192 && ws.prec) {
             ep.slab = nullptr;
             launch_tile<LA, LB, 2, 4, 4, 2>(s, a, b, ep, M, N, nprob, 1, ws.prec);
             return;
@@ -111,30 +110,20 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         for (int n = 1; n <= 256 && n <= min_chunks / 4 && (n == 1 || n <= cap_ws); ++n) {
             const double rounds = std::ceil(tiles * n / slots);
             double len = rounds * ((min_chunks + n - 1) / n + 6);
-            // problems of unequal length (the rectangle-ordered filter gradient: border taps see 9/16 of a 4x4 grid's pixels, `min_chunks`
-            // is their MEAN): a launch cannot end before its longest block, which one round of blocks does not average away -- without
-            // this term d_h1's filter gradient (400 tiles, one round, 144..256 chunks per block) ran unsplit at the pace of its
-            // longest tap (0.87 ms)
-            // ... and yet it is OFF (CTX_SPLIT_MAXTERM=1 turns it on): with it d_h1's filter gradient takes 0.70 ms instead of 0.87 alone
-            // (154 TF/s) and the three launches it changes save 0.24 ms serialised, but the STEP gets 0.1 ms longer (three A/B pairs on one
-            // box: 13.37 / 13.39 / 13.41 without, 13.47 / 13.48 / 13.51 with).  The unsplit launch's idle CUs are not idle in a step --
-            // the other lanes' kernels run there -- while the split adds slab traffic and a combine launch: work, which the step pays.
-            static const bool maxterm = [] { const char* e = getenv("CTX_SPLIT_MAXTERM"); return e && e[0] == '1'; }();
-            if (maxterm && max_chunks > min_chunks) { const double longest = (max_chunks + n - 1) / n + 6; if (longest > len) len = longest; }
+            // (a longest-problem term -- a launch cannot end before its longest block -- made d_h1's filter gradient 0.87 -> 0.70 ms alone and
+            // the STEP 0.1 ms longer in three A/B pairs, round 3: the unsplit launch's idle CUs are not idle in a step; not kept)
             double t = len * t_chunk;
-            // slab out + in, + the combine launch.  Weight (CTX_SPLIT_SLABW): in the exact-f32 mode a quarter of the estimate -- measured
-            // on whole steps, not launches: 1, 0.7, 0.5 and 0.25 give the same step (13.45-13.49 ms) while 0.25 takes 0.19 ms off the
-            // filter-gradient launches run alone; 2, 4, 8 cost +0.05, +0.15, +0.3 ms of step.  The split-bf16 mode keeps 1 (0.25: +0.1 ms).
-            static const double slabw_env = [] { const char* e = getenv("CTX_SPLIT_SLABW"); return e ? atof(e) : 0.0; }();
-            const double slabw = slabw_env > 0.0 ? slabw_env : ws.prec ? 1.0 : 0.25;
+            // slab out + in, + the combine launch.  Weight: in the exact-f32 mode a quarter of the estimate -- measured on whole steps, not
+            // launches (round 3): 1, 0.7, 0.5 and 0.25 give the same step while 0.25 takes 0.19 ms off the filter-gradient launches run
+            // alone; 2, 4, 8 cost +0.05, +0.15, +0.3 ms of step.  The split-bf16 mode keeps 1 (0.25: +0.1 ms).
+            const double slabw = ws.prec ? 1.0 : 0.25;
             if (n > 1) t += slabw * (2.0 * n * nprob * (double)M * N * 4 / 3e12 + 4e-6);
             if (t < best * 0.97) { best = t; nsplit = n; }                        // prefer fewer splits on near-ties
         }
     }
     ep.slab = nsplit > 1 ? ws.slab : nullptr;
-    {   // CTX_TRACE_LAUNCH=1: one stderr line per distinct launch shape (diagnostics)
-        static const bool trace = [] { const char* e = getenv("CTX_TRACE_LAUNCH"); return e && e[0] == '1'; }();
-        if (trace) {
+    {   // option "trace_launch": one stderr line per distinct launch shape (diagnostics)
+        if (opt(OPT_TRACE_LAUNCH)) {
             static std::mutex mu;
             static std::set<std::string> seen;
             char buf[256];
@@ -145,7 +134,7 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
         }
     }
     {   // problems of unequal length behind the XCD swizzle: balanced runs per XCD (launch.h: balanced_order).  The 8 XCDs share the
-        // nsplit x nprob slots in order, so one split's problems are spread over 8 / nsplit of them.  CTX_BALANCE=0: plain order.
+        // nsplit x nprob slots in order, so one split's problems are spread over 8 / nsplit of them.  Option "balance".
         if (prob_weight && ep.xcd_swizzle && !ep.swz_group && nprob >= 8) {
             const int nbins = nsplit <= 1 ? 8 : 8 % nsplit == 0 ? 8 / nsplit : 1;
             // (the heavy / light pairing distance only matters for a launch of about one round of resident blocks; a longer one gets

@@ -43,7 +43,44 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
     }
 }
 
-int balance_bits() { static const int v = [] { const char* e = getenv("CTX_BALANCE"); return e ? atoi(e) : 3; }(); return v; }
+// ---- per-handle options (options.h) -----------------------------------------------------------------------------------------
+namespace {
+struct OptDef { const char* name; int def; };
+const OptDef kOpts[OPT_COUNT] = {
+    {"overlap", 1}, {"graphs", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 15}, {"direct3", 15}, {"dconv", 1},
+    {"rchain", 1}, {"early_adam", 0}, {"cnn_lanes", -1}, {"cnn_stem4", 1}, {"trace_launch", 0},
+};
+}  // namespace
+thread_local const Options* g_opt = nullptr;
+const char* opt_name(int i) { return i >= 0 && i < OPT_COUNT ? kOpts[i].name : nullptr; }
+int opt_find(const char* name) {
+    if (!name) return -1;
+    if ((name[0] == 'C' || name[0] == 'c') && (name[1] == 'T' || name[1] == 't') && (name[2] == 'X' || name[2] == 'x') && name[3] == '_') name += 4;
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        const char *a = kOpts[i].name, *b = name;
+        while (*a && *b && (*a == *b || *a == *b + 32)) { ++a; ++b; }       // (option names are lower case; `name` may be upper case)
+        if (!*a && !*b) return i;
+    }
+    return -1;
+}
+Options options_from_env() {
+    Options o;
+    for (int i = 0; i < OPT_COUNT; ++i) {
+        char var[64] = "CTX_";
+        int k = 4;
+        for (const char* p = kOpts[i].name; *p && k < 62; ++p) var[k++] = (char)(*p >= 'a' && *p <= 'z' ? *p - 32 : *p);
+        var[k] = 0;
+        const char* e = getenv(var);
+        o.v[i] = e && *e ? atoi(e) : kOpts[i].def;
+    }
+    return o;
+}
+int opt(Opt o) {
+    if (g_opt) return g_opt->v[o];
+    static const Options first = options_from_env();
+    return first.v[o];
+}
+int balance_bits() { return opt(OPT_BALANCE); }
 
 const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem) {
     if (nprob <= 1 || nprob > 65535 || nbins < 1) return nullptr;
@@ -631,7 +668,7 @@ void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, 
     int nsl = (int)((rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8));
     // 128 slabs, not the 512 that make this kernel fastest alone (0.30 vs 0.26 ms per step): it runs on the side lane beside
     // the MFMA-bound chain, and the fewer CU slots it takes the less it slows that chain (whole step 14.50 vs 14.68 ms; tools/colsum_ab.sh)
-    static const int cap = [] { const char* e = getenv("CTX_COLSUM_SPLITS"); const int v = e ? atoi(e) : 128; return v < 1 ? 1 : v > COLSUM_SPLITS ? COLSUM_SPLITS : v; }();
+    constexpr int cap = 128 < COLSUM_SPLITS ? 128 : COLSUM_SPLITS;   // (512 row slabs make the column sums faster alone and the step slower: round 1, tools/colsum_ab.sh)
     if (nsl > cap) nsl = cap;
     if (nsl < 1) nsl = 1;
     const int64_t rows_per = (rows + nsl - 1) / nsl;

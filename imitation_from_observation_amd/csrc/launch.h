@@ -7,6 +7,8 @@
 #include "igemm.h"
 #include "dconv.h"
 
+#include "options.h"
+
 namespace ctx {
 
 // A launcher that cannot run its kernel (no tile fits, ...) records the reason here instead of printing or aborting inside a shared
@@ -99,7 +101,7 @@ void c3conv(hipStream_t s, const float* x, int nimg, int hin, int win, int strid
 
 // conv2d_transpose 5x5 stride 2 for wide channel counts on the 8x8 / 16x16 grids: image-major, input halo tile resident in LDS
 // (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
-bool wconvt_ok(int hs, int ws, int c1, int c2, int ca);
+bool wconvt_ok(int hs, int ws, int c1, int c2, int ca, int nimg);
 void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
                 const Epi& ep, SplitWs ws_);
 

@@ -1,0 +1,40 @@
+// options.h -- the library's tuning switches, per handle (include/ctxtrans.h: ctx_set_option / ctx_get_option).
+// A handle copies the process defaults at ctx_create / ctx_cnn_create; the defaults are the environment variables CTX_<NAME> read at
+// that moment (unset = the built-in default).  The launchers read the CALLING handle's options through a thread-local pointer that the
+// C ABI's entry points set (ctx::OptScope), so two handles in one process can run different settings.
+#pragma once
+
+namespace ctx {
+
+enum Opt {
+    OPT_OVERLAP,       // 1: the step runs on three stream lanes (conv_context chain, filter / bias gradients beside the dx chain); 0: one stream
+    OPT_GRAPHS,        // 1: the inference fetches at B <= 64 and the CNN front end replay captured hipGraphs
+    OPT_POSMAJOR,      // 1: position-major convolutions (only the taps inside the grid) at >= 64 images
+    OPT_XCD_SWIZZLE,   // bits: 1 position-major conv, 2 position-major transposed conv, 4 rectangle-ordered filter gradient: contiguous runs of work per XCD
+    OPT_BALANCE,       // bits: 1 load-balanced problem order on <= 16-position grids, 2 on larger grids, 4 for the filter gradient's taps
+    OPT_WCONVT,        // bits: 1 LDS-resident transposed conv (wconvt.hip), 2 row blocks on 4x4 grids, 4 row blocks on 8x8 grids, 8 column-uniform waves
+    OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3)
+    OPT_DCONV,         // 1: ContextAEReal in f32 on the narrow-channel direct kernels (dconv.h)
+    OPT_RCHAIN,        // 1: ContextAEReal's FC middle in three launches (rchain.hip)
+    OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused steps (bit-identical; measured: no gain)
+    OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
+    OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
+    OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)
+    OPT_COUNT
+};
+
+struct Options { int v[OPT_COUNT]; };
+
+const char* opt_name(int i);                 // lower-case name, e.g. "wconvt"; the environment variable is CTX_ + upper case
+int opt_find(const char* name);              // index or -1 (case-insensitive, with or without the CTX_ prefix)
+Options options_from_env();                  // built-in defaults overridden by the environment, read now
+extern thread_local const Options* g_opt;    // the calling handle's options (null: options_from_env() of the first use)
+int opt(Opt o);
+
+struct OptScope {                            // entry points: `OptScope os(&h->opt);`
+    const Options* prev;
+    explicit OptScope(const Options* o) : prev(g_opt) { g_opt = o; }
+    ~OptScope() { g_opt = prev; }
+};
+
+}  // namespace ctx

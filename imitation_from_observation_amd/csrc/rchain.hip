@@ -415,8 +415,7 @@ __global__ __launch_bounds__(RC_T) void rchain_dw_kernel(const RcW A) {
 }  // namespace
 
 bool rchain_ok(int Fp, int64_t D0p, int nset, bool drop, int prec) {
-    static const bool on = [] { const char* e = getenv("CTX_RCHAIN"); return !(e && e[0] == '0'); }();
-    return on && Fp == RC_F && nset == 1 && !drop && prec == 0 && D0p % 64 == 0 && D0p >= 64 && D0p <= 4096;
+    return opt(OPT_RCHAIN) && Fp == RC_F && nset == 1 && !drop && prec == 0 && D0p % 64 == 0 && D0p >= 64 && D0p <= 4096;
 }
 
 static size_t rc_fwd_lds(int D0p) { return (size_t)(RC_RE * (D0p + 4) + (2 * RC_RE + RC_TB + 2 * RC_TB) * 132 + 2 * 8192) * sizeof(float); }

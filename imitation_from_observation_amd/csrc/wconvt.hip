@@ -537,12 +537,12 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_row_kernel(const WcT P) 
     // Order inside an XCD: ROW-major -- all interior rows (25 taps) of its groups first, then the last rows (20), then the first (15).
     // A launch of these layers is about one round of resident blocks (two per CU), so its time is that of the slowest CU: with the
     // long blocks dispatched first every CU gets a long one, and the short ones fill the second slots -- a (25, 15..20)-tap pair
-    // shares the matrix pipe instead of two 25-tap blocks on one CU and two short ones on another.  CTX_WCONVT_ROW_ORDER=1 (P.ksplit
-    // carries it) restores the group-major order (a group's rows adjacent in the XCD's L2).
+    // shares the matrix pipe instead of two 25-tap blocks on one CU and two short ones on another (whole step 13.32 -> 13.20 ms against
+    // the group-major order, profiles/round4_a_ab_row_blocks.txt).
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
     const int nig = (P.nimg + G::IMGT - 1) / G::IMGT, nigl = (nig + 7) / 8;
     const int nt = l % P.gn, q = l / P.gn;
-    const int rsel = P.ksplit == 1 ? q / nigl : q % HS, ig = (P.ksplit == 1 ? q % nigl : q / HS) * 8 + xcd;
+    const int rsel = q / nigl, ig = (q % nigl) * 8 + xcd;
     if (ig >= nig) return;
     // interior rows first, the shorter border rows behind them
     const int r = rsel < HS - 2 ? rsel + 1 : rsel == HS - 2 ? HS - 1 : 0;
@@ -577,13 +577,13 @@ void launch_wc(hipStream_t s, const WcT& P) {
 
 }  // namespace
 
-// the shapes this kernel is instantiated for (everything else stays on the implicit GEMM)
-bool wconvt_ok(int hs, int ws, int c1, int c2, int ca) {
-    static const bool on = [] { const char* e = getenv("CTX_WCONVT"); return !(e && e[0] == '0'); }();
-    // 4x4 grids (8 images per tile, 32-wide column tiles so that the launch has 512 blocks): layer times equal to the class-major
-    // implicit GEMM when timed alone, the whole step 0.08 ms faster (13.72 vs 13.81 ms).  CTX_WCONVT_4X4=0 keeps them off.
-    static const bool on4 = [] { const char* e = getenv("CTX_WCONVT_4X4"); return !(e && e[0] == '0'); }();
-    return on && ((hs == 4 && ws == 4 && on4) || (hs == 8 && ws == 8) || (hs == 16 && ws == 16)) && c1 > 0 && c1 % 32 == 0 && c2 % 32 == 0 && ca % 32 == 0;
+// the shapes this kernel is instantiated for (everything else stays on the implicit GEMM).  Option "wconvt" bit 1.
+// nimg: the epilogue and the loaders address a tensor with 32-bit byte offsets ((pixel * ld + n) * 4): the largest of the launch's
+// tensors -- output / mask / skip-gradient terms at 4 hs ws pixels x ca channels, inputs at hs ws x max(c1, c2) -- must stay below 4 GiB
+bool wconvt_ok(int hs, int ws, int c1, int c2, int ca, int nimg) {
+    const int64_t out_bytes = (int64_t)nimg * 4 * hs * ws * ca * 4, in_bytes = (int64_t)nimg * hs * ws * (c1 > c2 ? c1 : c2) * 4;
+    return (opt(OPT_WCONVT) & 1) && ((hs == 4 && ws == 4) || (hs == 8 && ws == 8) || (hs == 16 && ws == 16)) && c1 > 0 && c1 % 32 == 0 && c2 % 32 == 0 &&
+           ca % 32 == 0 && out_bytes < (1ll << 32) && in_bytes < (1ll << 32);
 }
 
 void splitk_reduce(hipStream_t s, const Epi& ep, int M, int N, int nprob, int nsplit);     // kernels.hip
@@ -593,43 +593,37 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
     WcT P{s1, c1, s2, c2, nmod2 > 0 ? nmod2 : 1, w, ca, nimg, 1, 1, nullptr, ep};
     const int img_per = hs * ws >= 128 ? 1 : 128 / (hs * ws), tpi = hs * ws >= 128 ? hs * ws / 128 : 1;
     const int64_t ntile = (int64_t)((nimg + img_per - 1) / img_per) * tpi;
-    static const int force_nb = [] { const char* e = getenv("CTX_WCONVT_NB"); return e ? atoi(e) : 0; }();     // A/B switches
-    static const int force_ks = [] { const char* e = getenv("CTX_WCONVT_KSPLIT"); return e ? atoi(e) : 0; }();
-    // 64 output channels per block (half the filter traffic of 32).  A launch should offer >= ~400 blocks to the chip's 512 slots: where
-    // tiles x column tiles fall short (the 4x4 grids: 8 images per tile; the 256-image conv_context launches) the channel slices are
-    // split over 2 or 4 blocks whose partial sums meet in splitk_reduce (output-sized slabs: a few % of the layer).
+    // 64 output channels per block (half the filter traffic of 32) where tiles x column tiles still offer >= ~400 blocks to the chip's
+    // 512 slots; else 32-wide column tiles.  Splitting the channel slices of a FULL launch over 2-4 blocks (partial sums through slabs)
+    // was measured on whole steps in round 3 and does not pay (13.75 vs 13.72 ms: faster alone, not beside the side lanes).
     const int nsl = (c1 + c2) / 32;
     const int64_t npix = (int64_t)nimg * 4 * hs * ws;
     bool nb2 = ca % 64 == 0;
-    if (force_nb) nb2 = nb2 && force_nb == 2;
     int ks = 1;
-    static const int ks_max = [] { const char* e = getenv("CTX_WCONVT_KSMAX"); return e ? atoi(e) : 4; }();
-    // Measured (B = 256, whole step, three runs each): splitting the 4x4 launches makes THEM faster when timed alone (d_h1 forward 0.82 ->
-    // 0.78 ms, conv_context h3 dx 0.31 -> 0.23) but the step no faster (13.75 vs 13.72 ms): they share the chip with the side lanes, and the
-    // slabs + reduce launches take from those.  So the default is no split (narrower column tiles instead); CTX_WCONVT_KSGRID=16 turns it on.
     const int slots400 = dev_info().cus * 2 * 25 / 32;                     // ~ 78 % of the resident block slots (400 of 512 on MI355X)
-    static const int ks_grid = [] { const char* e = getenv("CTX_WCONVT_KSGRID"); return e ? atoi(e) : 0; }();    // largest grid (positions) that may split
-    while (hs * ws <= ks_grid && ks < ks_max && ntile * (ca / (nb2 ? 64 : 32)) * ks < slots400 && nsl / (2 * ks) >= 4 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
-    if (force_ks) ks = force_ks;
-    if (ks == 1 && nb2 && !force_nb && ntile * (ca / 64) < slots400) nb2 = false;        // no room to split: narrower column tiles instead
-    // row blocks (above).  CTX_WCONVT_ROW: 0 = off (all-taps tiles everywhere), bit 1 = the 4x4 grids, bit 2 = the 8x8 grids;
-    // CTX_WCONVT_ROW_PB = 64 | 128 forces a tile shape on the 4x4 grids.
-    static const int rowk = [] { const char* e = getenv("CTX_WCONVT_ROW"); return e ? atoi(e) : 3; }();
-    static const int rowpb = [] { const char* e = getenv("CTX_WCONVT_ROW_PB"); return e ? atoi(e) : 0; }();
-    if (ks == 1 && !force_nb && ca % 64 == 0 && ((hs == 4 && (rowk & 1)) || (hs == 8 && (rowk & 2)))) {
-        static const bool gmajor = [] { const char* e = getenv("CTX_WCONVT_ROW_ORDER"); return e && e[0] == '1'; }();
-        P.ksplit = gmajor ? 2 : 1;                                 // (the row kernel does not split K: the field carries its block order)
+    // STARVED launches (the reward hook's batch of 25: d_h1 offers 16-32 blocks to 256 CUs and each walks 32 slices x 25 taps alone --
+    // 0.45 ms of a 1.4 ms translate call, profiles/round4_b_reward_trace_before.txt): 32-wide column tiles and the channel slices over
+    // up to 8 blocks, whatever the grid.
+    const bool starved = ntile * (ca / 64) * 2 <= dev_info().cus;
+    if (starved) {
+        nb2 = false;
+        while (ks < 8 && ntile * (ca / 32) * ks < dev_info().cus && nsl / (2 * ks) >= 2 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
+    }
+    // row blocks (above): option "wconvt" bit 2 = the 4x4 grids, bit 4 = the 8x8 grids, bit 8 = column-uniform waves on the 4x4 grids
+    const int wopt = opt(OPT_WCONVT);
+    if (ks == 1 && ca % 64 == 0 && ((hs == 4 && (wopt & 2)) || (hs == 8 && (wopt & 4)))) {
+        P.ksplit = 1;
         P.slab = nullptr;
         if (hs == 8) launch_wr<8, 8, 64>(s, P);
         else {
             // 128-position tiles (the filter traffic of the all-taps kernel) where they still make ~2 blocks per CU; else 64 x 64
             const int64_t blocks128 = (int64_t)((nimg + 31) / 32) * 4 * (ca / 32);
-            const bool big = rowpb ? rowpb == 128 : blocks128 >= dev_info().cus * 2 * 3 / 4;
-            static const bool xs = [] { const char* e = getenv("CTX_WCONVT_XS"); return !(e && e[0] == '0'); }();      // column-uniform waves (x taps skipped too)
-            if (big && xs) launch_wr<4, 4, 128, true>(s, P); else if (big) launch_wr<4, 4, 128>(s, P); else launch_wr<4, 4, 64>(s, P);
+            const bool big = blocks128 >= dev_info().cus * 2 * 3 / 4;
+            if (big && (wopt & 8)) launch_wr<4, 4, 128, true>(s, P); else if (big) launch_wr<4, 4, 128>(s, P); else launch_wr<4, 4, 64>(s, P);
         }
         return;
     }
+    if (ks == 1 && nb2 && ntile * (ca / 64) < slots400) nb2 = false;        // narrower column tiles instead of a half-empty chip
     P.gn = nb2 ? ca / 64 : ca / 32;
     P.ksplit = ks;
     P.slab = ks > 1 ? wsp.slab : nullptr;

@@ -132,8 +132,41 @@ class TranslatorReward:
             return cf
         return cf + ci
 
-    def paths_costs(self, paths):
-        """costs[p][j] for every path, many paths per encoder launch."""
+    def _group(self, distributed):
+        """(rank, world, allsum) of the group a distributed call runs on: the translator's own RCCL group when it has one
+        (Translator.dp_init -- ctx_dp_allreduce_host_f64, no torch in the sampler process), else an initialised torch.distributed group."""
+        if not distributed:
+            return 0, 1, (lambda x: x)
+        own = getattr(self.tr, "dp_world", None)
+        if callable(own) and own()[1] > 1:
+            rank, world = own()
+            return rank, world, self.tr.dp_allreduce_host
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+
+        def allsum(x):
+            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+            if dist.get_backend() == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.cpu().numpy()
+        return rank, world, (allsum if world > 1 else (lambda x: x))
+
+    def paths_costs(self, paths, distributed=False):
+        """costs[p][j] for every path, many paths per encoder launch.
+        distributed=True (one rank per GPU, every rank holding the same `paths` and the same demo cache): the >= 250 rollout paths of a
+        TRPO iteration are sharded rank::world -- a path's cost depends on nothing but its own frames (base.py:232-249) -- and the
+        [npaths, bs] cost table is completed with ONE all-reduce (last sentence); every rank returns the full table."""
+        rank, world, allsum = self._group(distributed)
+        if world > 1:
+            if self.means is None:
+                raise RuntimeError("distributed paths_costs needs the demo cache first (build_demo_cache(..., distributed=True))")
+            mine = list(range(rank, len(paths), world))
+            part = np.zeros((len(paths), self.batch_size), np.float64)
+            if mine:
+                part[mine] = self.paths_costs([paths[i] for i in mine])
+            return allsum(part.ravel()).reshape(part.shape).astype(np.float32)
         bs = self.batch_size
         frames = [self._frames_of(p) for p in paths]
         for f in frames:
@@ -164,11 +197,15 @@ class TranslatorReward:
         return costs
 
     # ------------------------------------------------------------------ base.py:256-257
-    def process_paths(self, paths):
+    def process_paths(self, paths, distributed=False):
         """In place: path['rewards'][2j+1] -= costs[j] * j**2.  After set_demos(validdata) the demo cache is built lazily from
         the first path's first frame per viewpoint, as the reference does (base.py:195-200); otherwise build_demo_cache() must
-        have been called."""
-        costs = self.paths_costs(paths)
+        have been called.  distributed=True: the paths' costs are computed rank::world and gathered (paths_costs); every rank then
+        applies them to its copy of `paths`."""
+        if distributed and self.means is None and self.validdata is not None:
+            frames0 = self._frames_of(paths[0])
+            self.build_demo_cache(self.validdata, [frames0[0][vp] for vp in range(self.nvp)], distributed=True)
+        costs = self.paths_costs(paths, distributed=distributed)
         for p, c in zip(paths, costs):
             for j in range(self.batch_size):
                 p["rewards"][j * 2 + 1] -= c[j] * (j ** 2)

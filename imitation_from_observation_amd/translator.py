@@ -42,6 +42,34 @@ def _fp(a):
     return a.ctypes.data_as(_FP)
 
 
+class _ResultPool:
+    """Result arrays of the inference fetches, recycled.  A result above glibc's mmap threshold (32 MB: B >= 683 frames of 64x64x3 f32)
+    is a FRESH mapping every time numpy allocates it, whose pages fault in while the device copy lands -- 4.4 of the 8.5 ms of an
+    `encode` call at B = 1000 (tools/encode_cliff.py).  The pool hands out an array it made before as soon as nobody else holds it
+    any more (its reference count is back to the pool's own), so a caller that drops or overwrites the previous result -- the reward
+    hook's loop -- gets warm pages, and a caller that keeps results gets fresh arrays exactly as before: no aliasing either way.
+    Only arrays of >= `min_bytes` are pooled (small ones come from malloc's free lists and are warm anyway)."""
+
+    def __init__(self, min_bytes=1 << 20, keep=4):
+        self.min_bytes, self.keep, self._free = min_bytes, keep, {}
+
+    def get(self, shape, dtype=np.float32):
+        import sys
+        shape = tuple(int(v) for v in shape)
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if nbytes < self.min_bytes:
+            return np.empty(shape, dtype)
+        lst = self._free.setdefault((shape, np.dtype(dtype).str), [])
+        for a in lst:
+            # references: the list, the loop variable, getrefcount's argument -- anything more is a caller (or a view of one)
+            if sys.getrefcount(a) == 3:
+                return a
+        a = np.empty(shape, dtype)
+        if len(lst) < self.keep:
+            lst.append(a)
+        return a
+
+
 def _up(a):
     return a.ctypes.data_as(_UP)
 
@@ -81,6 +109,7 @@ class Translator:
             self._h = ctypes.c_void_p()
             raise CtxError(rc, msg.decode() if msg else "")
         self.n_params = int(self._lib.ctx_param_total(self._h))
+        self._pool = _ResultPool()
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -130,6 +159,21 @@ class Translator:
     def arena_floats(H=64, W=64, df_dim=64, featsize=1024, variant="skipnew", C=3, strides=None, kernels=None, filters=None):
         cfg = Translator.make_config(variant, H, W, C, df_dim, featsize, 1, "f32", strides, kernels, filters)
         return int(_lib.load().ctx_arena_bytes(ctypes.byref(cfg))) // 4
+
+    # ------------------------------------------------------------------ tuning switches (include/ctxtrans.h: per-handle options)
+    @staticmethod
+    def option_names():
+        lib = _lib.load()
+        return [lib.ctx_option_name(i).decode() for i in range(lib.ctx_option_count())]
+
+    def get_option(self, name):
+        v = ctypes.c_int()
+        self._ck(self._lib.ctx_get_option(self._h, name.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def set_option(self, name, value):
+        """This handle's switch `name` (e.g. "overlap", "balance", "wconvt"; the environment variable CTX_<NAME> is its default at create)."""
+        self._ck(self._lib.ctx_set_option(self._h, name.encode(), int(value)))
 
     # ------------------------------------------------------------------ parameters (tf.train.Saver)
     def param_info(self):
@@ -235,8 +279,8 @@ class Translator:
         batched = ctx0.ndim == 4
         if tuple(ctx0.shape) != ((B, self.H, self.W, 3) if batched else (self.H, self.W, 3)):
             raise ValueError(f"obs_tgt0 has shape {ctx0.shape}")
-        pred = np.empty((B, self.H, self.W, 3), np.float32)
-        feat = np.empty((B, self.featsize), np.float32)
+        pred = self._pool.get((B, self.H, self.W, 3))
+        feat = self._pool.get((B, self.featsize))
         self._ck(self._lib.ctx_translate(self._h, _up(src), _up(ctx0), int(batched), B, _fp(pred), _fp(feat)))
         return pred, feat
 
@@ -277,9 +321,9 @@ class Translator:
     def encode(self, frames, return_frames=True, out=None):
         """frames uint8 [B,H,W,3] -> (input_z f32 [B,featsize], image_trans[0] f32 [B,H,W,3]).
 
-        out = (feat, frames_f32): caller-owned result arrays to fill instead of fresh ones.  Above 32 MB (B >= 683 at 64x64) a
-        fresh numpy array is a fresh mmap whose pages fault in while the copy lands -- 4 ms of a 7.5 ms call at B = 1000
-        (tools/encode_cliff.py); a caller that encodes many paths per call should hand the same buffers back in."""
+        out = (feat, frames_f32): caller-owned result arrays to fill instead of the translator's.  (Large results come from a pool that
+        recycles an array once the caller has let go of it -- _ResultPool: a fresh > 32 MB numpy array is a fresh mmap whose pages
+        fault in while the copy lands, 4 ms of a 7.5 ms call at B = 1000.)"""
         fr = _u8(frames)
         if fr.ndim != 4 or fr.shape[1:] != (self.H, self.W, 3):
             raise ValueError(f"frames must be [B,{self.H},{self.W},3], got {fr.shape}")
@@ -291,8 +335,8 @@ class Translator:
             if return_frames and (f32 is None or f32.shape != fr.shape or f32.dtype != np.float32 or not f32.flags.c_contiguous):
                 raise ValueError("out[1] must be a C-contiguous float32 array of the frames' shape")
         else:
-            feat = np.empty((B, self.featsize), np.float32)
-            f32 = np.empty(fr.shape, np.float32) if return_frames else None
+            feat = self._pool.get((B, self.featsize))
+            f32 = self._pool.get(fr.shape) if return_frames else None
         self._ck(self._lib.ctx_encode(self._h, _up(fr), B, _fp(feat), _fp(f32) if return_frames else None))
         return feat, f32
 

@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define CTX_ABI_VERSION 2   /* 2: ctx_config carries strides / kernels / filters / keep_prob / loss_mode */
+#define CTX_ABI_VERSION 3   /* 2: ctx_config carries strides / kernels / filters / keep_prob / loss_mode; 3: per-handle options,
+                               ctx_dp_train_step_sampled / ctx_dp_eval_sampled, ctx_prof_entry.useful_frac */
 
 enum {
     CTX_OK = 0,
@@ -111,6 +112,30 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
 void ctx_destroy(ctx_handle* h);
 /* Message of the last failed call on `h` (or of the last failed ctx_create when h == NULL). */
 const char* ctx_last_error(const ctx_handle* h);
+
+/* ---- tuning switches, per handle ---------------------------------------------------------------
+ * Every switch is an int.  A handle starts from the built-in defaults overridden by the environment variables CTX_<NAME> (upper
+ * case) as they stand at ctx_create; ctx_set_option changes it for that handle only (two handles of one process may differ).
+ * Names (ctx_option_count / ctx_option_name enumerate them):
+ *   overlap      1   the step runs on three stream lanes (conv_context chain; filter / bias gradients beside the dx chain); 0 = one stream
+ *   graphs       1   the inference fetches at B <= 64 replay captured hipGraphs
+ *   posmajor     1   position-major convolutions (only the taps inside the grid) from 64 images up
+ *   xcd_swizzle  7   bits: contiguous runs of work per XCD for 1 the position-major conv, 2 the transposed conv, 4 the filter gradient
+ *   balance      3   bits: load-balanced problem order 1 on grids of <= 16 positions, 2 on larger grids, 4 for the filter gradient's taps
+ *   wconvt      15   bits: 1 LDS-resident transposed conv, 2 / 4 row blocks on 4x4 / 8x8 grids, 8 column-uniform waves (4x4)
+ *   direct3     15   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass  [fixed at create]
+ *   dconv        1   ContextAEReal in f32 on the narrow-channel direct kernels                                          [fixed at create]
+ *   rchain       1   ContextAEReal's FC middle in three launches
+ *   early_adam   0   Adam's slices beside the remaining backward in the fused steps (bit-identical; measured: no gain)
+ *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create)
+ *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create)
+ *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
+ * Results never depend on a switch beyond f32 summation order.  Not options: CTX_RCCL_LIB (path of the librccl to dlopen, read by the
+ * first ctx_dp_* call of the process). */
+int ctx_option_count(void);
+const char* ctx_option_name(int index);                               /* NULL past the end */
+int ctx_get_option(const ctx_handle* h, const char* name, int* value);
+int ctx_set_option(ctx_handle* h, const char* name, int value);       /* CTX_E_INVALID: unknown name; CTX_E_STATE: fixed at create */
 
 /* ---- parameter inventory (TF variable names) ------------------------------------------------ */
 int64_t ctx_param_total_for(const ctx_config* cfg); /* number of f32 parameters, <0 on error */
@@ -206,7 +231,7 @@ int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const
 /* One whole training step on device-resident frames: forward + backward + Adam (train_script.py:163's
  * sess.run([..., optim]) without the host copies), enqueued on the handle's stream, no synchronisation.
  * Same result, bit for bit, as ctx_dev_forward_backward(sim_batch = 0) followed by ctx_dev_adam(lr).  With
- * CTX_EARLY_ADAM=1 in the environment, Adam's update of a parameter slice is enqueued beside the remaining
+ * option "early_adam" set, Adam's update of a parameter slice is enqueued beside the remaining
  * backward as soon as that slice's gradients are final and its parameters are no longer read (measured: no
  * gain on MI355X, so off by default; still bit-identical).  The host-fed steps (ctx_train_step, _u8, _sampled)
  * go through the same code. */

@@ -119,12 +119,22 @@ def main():
     hook = TranslatorReward(trw, nvp=2, scale=0.01).build_demo_cache(validdata, first, distributed=True)
     out["cache_means"] = np.stack(hook.means)
     out["cache_imgs"] = np.stack(hook.imgs)
+    # ... and the rollout paths of an iteration sharded rank::world over the same group (base.py:232-257): 5 paths, 2 viewpoints
+    prng = np.random.default_rng(41)
+    paths = []
+    for _ in range(5):
+        imgs = []
+        for t in range(50):
+            imgs.append([prng.integers(0, 256, (H, W, 3), dtype=np.uint8) for _ in range(2)] if t % 2 == 0 else None)
+        paths.append({"env_infos": {"imgs": imgs}, "rewards": np.zeros(50)})
+    out["path_costs"] = hook.paths_costs(paths, distributed=True)
     if rank == 0:                                       # the same cache built by one rank alone
         solo = Translator(H, W, D, F, max_batch=50)
         solo.set_params_flat(out["params3"])
         h1 = TranslatorReward(solo, nvp=2, scale=0.01).build_demo_cache(validdata, first)
         out["solo_means"] = np.stack(h1.means)
         out["solo_imgs"] = np.stack(h1.imgs)
+        out["solo_path_costs"] = h1.paths_costs(paths)
         solo.close()
     trw.close()
     # (d) the ablation script's loss switch under data parallelism (ablations_code/ablations.py:175-182; ctx_config.loss_terms): "L1" =

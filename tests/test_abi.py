@@ -29,7 +29,7 @@ def test_ctypes_table_matches_header(built_lib, repo_root):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.ctx_abi_version() == 2
+    assert built_lib.ctx_abi_version() == 3
 
 
 def test_param_total_is_the_references(built_lib):
@@ -87,3 +87,42 @@ def test_checkpoint_paths_without_extension_resolve_to_one_file(tmp_path):
     assert Translator.checkpoint_file(p) == p + ".npz"
     assert Translator.checkpoint_file(p + ".npz") == p + ".npz"
     assert Translator.checkpoint_file(tmp_path / "ck.npz") == str(tmp_path / "ck.npz")
+
+
+def test_result_pool_recycles_only_released_arrays():
+    """Translator's result arrays above the pool's threshold are recycled once the caller has let go of them (warm pages instead of a
+    fresh > 32 MB mapping per call) and never while anything -- the array itself or a view of it -- is still held."""
+    import numpy as np
+    from imitation_from_observation_amd.translator import _ResultPool
+    pool = _ResultPool(min_bytes=1024)
+    a = pool.get((64, 64))
+    ida = id(a)
+    b = pool.get((64, 64))
+    assert b is not a                                   # `a` is still held: a second array
+    del a
+    c = pool.get((64, 64))
+    assert id(c) == ida                                 # released: recycled
+    view = c[:4]
+    del c
+    d = pool.get((64, 64))
+    assert id(d) != ida and view.base is not None       # a view keeps its base out of circulation
+    small = pool.get((4, 4))
+    assert pool.get((4, 4)) is not small                # below the threshold: plain np.empty
+
+
+def test_options_are_enumerable_and_documented(built_lib):
+    """Every per-handle switch the library knows (ctx_option_count / ctx_option_name) is documented in include/ctxtrans.h, and no
+    other CTX_* environment variable is read by the kernels' sources (only CTX_RCCL_LIB, the dlopen path)."""
+    import glob
+    import re
+    names = [built_lib.ctx_option_name(i).decode() for i in range(built_lib.ctx_option_count())]
+    assert len(names) == len(set(names)) >= 10 and built_lib.ctx_option_name(len(names)) is None
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(ROOT, "include", "ctxtrans.h")).read()
+    for n in names:
+        assert re.search(r"^\s\*\s+%s\s+-?\d+\s" % re.escape(n), header, re.M), f"option {n} is not documented in include/ctxtrans.h"
+    env = set()
+    for f in glob.glob(os.path.join(ROOT, "imitation_from_observation_amd", "csrc", "*")):
+        if f.endswith((".hip", ".h", ".cpp", ".inc")):
+            env |= set(re.findall(r'getenv\("(CTX_[A-Z0-9_]+)"\)', open(f).read()))
+    assert env == {"CTX_RCCL_LIB"}, env

@@ -134,7 +134,11 @@ def _reward_worker(rank, world, port, q):
     p, validdata, paths = make_world(nvp=2, nvid=7, npaths=2, seed=5)
     first = [img for img in paths[0]["env_infos"]["imgs"] if img is not None][0]
     hook = TranslatorReward(OracleTranslator(p, 50), nvp=2, scale=0.01).build_demo_cache(validdata, first, distributed=True)
-    q.put((rank, [m.copy() for m in hook.means], [i.copy() for i in hook.imgs]))
+    # the per-path costs sharded the same way (base.py:232-257): 5 paths on 2 ranks, one all-reduce, then the rewards
+    _, _, paths5 = make_world(nvp=2, nvid=7, npaths=5, seed=5)
+    costs = hook.paths_costs(paths5, distributed=True)
+    hook.process_paths(paths5, distributed=True)
+    q.put((rank, [m.copy() for m in hook.means], [i.copy() for i in hook.imgs], costs, [p_["rewards"].copy() for p_ in paths5]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -163,3 +167,12 @@ def test_demo_cache_sharded_over_ranks_equals_single_process():
             np.testing.assert_allclose(got[r][1][vp], ref.means[vp], rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(got[r][2][vp], ref.imgs[vp], rtol=1e-5, atol=1e-7)
     np.testing.assert_array_equal(got[0][1][0], got[1][1][0])      # every rank ends with the same cache
+    # sharded per-path costs = the single-process hook's, on every rank; rewards updated alike
+    _, _, paths5 = make_world(nvp=2, nvid=7, npaths=5, seed=5)
+    want = ref.paths_costs(paths5)
+    ref.process_paths(paths5)
+    for r in range(world):
+        np.testing.assert_allclose(got[r][3], want, rtol=1e-5, atol=1e-7)
+        for a, b in zip(got[r][4], (p_["rewards"] for p_ in paths5)):
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(got[0][3], got[1][3])

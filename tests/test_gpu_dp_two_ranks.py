@@ -148,3 +148,8 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
     assert both.shape == z[0]["solo_eval_out"].shape
     assert np.abs(both - z[0]["solo_eval_out"]).max() <= 1e-4 * np.abs(z[0]["solo_eval_out"]).max()
     np.testing.assert_allclose(z[0]["samp_eval"][[0, 2, 3]], z[0]["solo_eval"][[0, 2, 3]], rtol=1e-4)
+    # ---- the per-path costs of the reward hook sharded over the two ranks (TranslatorReward.paths_costs(distributed=True)): every
+    # rank ends with the full [paths, 25] table, equal to what one rank computes for all paths
+    np.testing.assert_array_equal(z[0]["path_costs"], z[1]["path_costs"])
+    assert z[0]["path_costs"].shape == (5, 25) and np.abs(z[0]["path_costs"]).max() > 0
+    np.testing.assert_allclose(z[0]["path_costs"], z[0]["solo_path_costs"], rtol=1e-5, atol=1e-6)

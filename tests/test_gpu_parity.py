@@ -409,8 +409,9 @@ def test_fused_step_with_adam_beside_the_backward_is_bit_identical(T, variant, H
     kw = dict(df_dim=d, featsize=F, max_batch=B) if variant == "skipnew" else dict(featsize=F, max_batch=B, variant="real")
     res = []
     for fused in (True, False):
-        os.environ["CTX_EARLY_ADAM"] = "1" if fused else "0"      # (read at every step)
         with T(H, W, **kw) as tr:
+            tr.set_option("early_adam", 1 if fused else 0)          # per-handle switch (include/ctxtrans.h: ctx_set_option)
+            assert tr.get_option("early_adam") == (1 if fused else 0)
             tr.init_params(5)
             for _ in range(3):
                 if fused:
@@ -421,7 +422,6 @@ def test_fused_step_with_adam_beside_the_backward_is_bit_identical(T, variant, H
             sc = tr.dev_scalars()
             m, v, t = tr.get_adam_state()
             res.append((tr.get_params_flat(), m, v, t, sc))
-    os.environ.pop("CTX_EARLY_ADAM", None)
     assert res[0][3] == res[1][3] == 3 and res[0][4] == res[1][4]
     for a, b in zip(res[0][:3], res[1][:3]):
         np.testing.assert_array_equal(a, b)
