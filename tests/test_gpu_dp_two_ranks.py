@@ -138,10 +138,16 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
     dev = np.abs(a - b)
     print("sampled DP vs one handle after 3 steps: max |dp| / max |p| =", dev.max() / np.abs(b).max(), " rel-L2 =", np.linalg.norm(a - b) / np.linalg.norm(b),
           " entries beyond 1e-6 of max |p|:", int((dev > 1e-6 * np.abs(b).max()).sum()), "of", a.size)
-    # (Adam's first steps move every entry by ~lr whatever the size of its gradient, so an entry whose two f32 gradients differ in
-    # sign -- a gradient at the rounding floor -- ends 2 lr apart: those are counted, everything else agrees to 1e-6)
-    assert (dev > 1e-6 * np.abs(b).max()).mean() <= 1e-4
-    assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+    # The two runs use different launches (8 triples per rank against 16 on the single handle: other tiles, split-K where a launch would
+    # starve the chip), so their f32 sums differ in the last bits and Adam -- whose first steps move every entry by ~lr whatever the size
+    # of its gradient -- turns a gradient at the rounding floor into a visibly different step.  Bounds: the parameters agree to 5e-6
+    # relative (L2), no entry is further apart than a fraction of ONE Adam step (a sign flip would be 2 x 3 lr = 6e-4), and the UPDATE
+    # itself (what three steps changed) agrees to 1e-3.
+    upd_a, upd_b = a - z[0]["params0"].astype(np.float64), b - z[0]["params0"].astype(np.float64)
+    print("   update agreement |d_dp - d_solo| / |d_solo| =", np.linalg.norm(upd_a - upd_b) / np.linalg.norm(upd_b))
+    assert np.linalg.norm(a - b) <= 5e-6 * np.linalg.norm(b)
+    assert dev.max() <= 0.5 * 1e-4                                   # half of one lr = 1e-4 step
+    assert np.linalg.norm(upd_a - upd_b) <= 1e-3 * np.linalg.norm(upd_b)
     # the sharded validation fetch: global scalars, and the two ranks' rows side by side = the single handle's outputs
     np.testing.assert_array_equal(z[0]["samp_eval"], z[1]["samp_eval"])
     both = np.concatenate([z[0]["samp_eval_out"], z[1]["samp_eval_out"]])
