@@ -13,7 +13,9 @@ def group(k):
     if not m:
         if "adam_kernel" in k:
             return "adam"
-        d = re.match(r"void ctx::(?:\(anonymous namespace\)::)?(dconv_fwd_kernel|dconv_wgrad_kernel|convt3_kernel|wconvt_kernel|c3conv_kernel|c3wgrad_kernel)<", k)     # the labels ctx_profile_step uses for the direct kernels
+        d = re.match(r"void ctx::(?:\(anonymous namespace\)::)?(dconv_fwd_kernel|dconv_wgrad_kernel|convt3_kernel|wconvt_kernel|wconvt_row_kernel|c3conv_kernel|c3wgrad_kernel)<", k)     # the labels ctx_profile_step uses for the direct kernels
+        if d and d.group(1) == "wconvt_row_kernel":          # the row-block instances of the same layer family: one label (ctx_profile_step's)
+            return "wconvt_kernel"
         return d.group(1) if d else k
     a, b = m.group(2), m.group(3)
     if a.startswith("KmConvTGather"):

@@ -6,7 +6,7 @@ TAG=${1:-x}; PREC=${2:-f32}
 R=$PWD; O=$R/gpurun_out/$TAG/pmc_hbm_$PREC; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  CTX_OVERLAP=0 timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split-leg --no-secondary --sustained-s 0 --kernel-iters 1 --precision $PREC > $O/$C.log 2>&1
+  CTX_OVERLAP=0 timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/$C -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-split-leg --no-secondary --no-sampled --sustained-s 0 --kernel-iters 1 --precision $PREC > $O/$C.log 2>&1
 done
 cd $R
 SUF=""; [ "$PREC" != "f32" ] && SUF="_$PREC"

@@ -9,8 +9,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1
 python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err
-BENCH_LAYER_TABLE=$O/layer_table.txt python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --sustained-s 0 > /dev/null 2>&1
-BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --sustained-s 0 > $O/bench_force_dist.json 2> /dev/null
+BENCH_LAYER_TABLE=$O/layer_table.txt python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --no-sampled --sustained-s 0 > /dev/null 2>&1
+BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --no-sampled --sustained-s 0 > $O/bench_force_dist.json 2> /dev/null
 python tools/bench_reward.py > $O/reward.txt 2>&1
 python tools/bench_real.py > $O/real.txt 2>&1
 python tools/real_layer_table.py > $O/real_layers.txt 2>&1
@@ -18,9 +18,9 @@ python tools/bench_config4.py 125 64 > $O/config4.txt 2>&1
 python tools/frontend_layer_table.py > $O/frontend_layers.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernels serialised on one stream (CTX_OVERLAP=0) so per-kernel durations are comparable with bench.py's event table
-CTX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --sustained-s 0 > $O/rp.log 2>&1
+CTX_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-sampled --no-split-leg --sustained-s 0 > $O/rp.log 2>&1
 # the same with the three stream lanes on (what a normal step runs)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_lanes -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --sustained-s 0 > $O/rp_lanes.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/rp_lanes -o r1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-sampled --no-split-leg --sustained-s 0 > $O/rp_lanes.log 2>&1
 cd $R
 rm -f $O/rp/*kernel_trace.csv $O/rp_lanes/*kernel_trace.csv
 bash tools/pmc_kernel.sh wconvt_kernel $TAG > /dev/null 2>&1
