@@ -13,8 +13,10 @@ Same constructor arguments, same loop (`train_script.py:144-203`):
   * from `save_every` on, every validation appends a row Iteration, Loss, Sim, R1, R2, NNErr to the tabular log (:196-203).
 
 What differs, and why:
-  * the mp4 -> vdata step (:59-96) needs imageio/ffmpeg and scipy.misc.imresize, neither present: the demo tensor comes
-    in as an array or a `.npy` path (the file the reference itself saves);
+  * mp4 DECODING (:69, imageio + ffmpeg) is not available here: the demo tensor comes in as an array or a `.npy` path (the file
+    the reference itself saves), or as `videos=` -- decoded videos [51, H, W, 3] uint8 -- which then go through the reference's own
+    loop (:59-96: frame selection by nskip, `transform` = scipy.misc.imresize bilinear + /127.5 - 1, black-frame drop; restated in
+    demo_pipeline.py, the resize bit-exact against Pillow) and are saved as `<basedir>vdata_strike<n>.npy` like :95;
   * the sess.run calls are `Translator.train_step_sampled` / `eval_sampled` on the demo tensor resident in HBM (uint8;
     `gather_triples_kernel` builds the batch with the trainer's x / 127.5 - 1 scaling) when the float demo tensor lies
     exactly on that uint8 lattice -- bit-identical to feeding the host-gathered float batch -- and
@@ -78,7 +80,7 @@ class ModelTrainer:
 
     def __init__(self, idims, nvideos, ntrain, batch_size, model, nitr, save_every, nlen, nskip, rescale=True, inception=False,
                  strides=None, kernels=None, filters=None, *, vdata=None, basedir="model/", device=0, seed=0, translator=None,
-                 precision=None, log=print, rank=0, world=1, dp_unique_id=None):
+                 precision=None, log=print, rank=0, world=1, dp_unique_id=None, videos=None):
         """The reference's 14 positional arguments (train_script.py:29-30; the launchers omit the last five, SURVEY.md 3.4-b,
         hence the defaults), then: vdata (array or .npy path of the demo tensor), basedir (logger._snapshot_dir), device,
         seed of the parameter initialiser, an optional ready-made translator (tests), the arithmetic, the log sink.
@@ -92,6 +94,7 @@ class ModelTrainer:
         self.rescale, self.inception = rescale, inception
         self.strides, self.kernels, self.filters = strides, kernels, filters
         self.vdata, self.basedir, self.device, self.seed = vdata, basedir, device, seed
+        self.videos = videos       # decoded demo videos (arrays [51, H, W, 3] uint8 or callables returning them): train_script.py:59-96
         self.translator, self.precision, self.log = translator, precision, log
         self.rank, self.world, self.dp_unique_id = int(rank), int(world), dp_unique_id
         if self.world < 1 or not 0 <= self.rank < self.world:
@@ -141,7 +144,14 @@ class ModelTrainer:
     def train(self):
         basedir = self.basedir if self.basedir.endswith("/") else self.basedir + "/"
         os.makedirs(basedir, exist_ok=True)
-        vdata = np.load(self.vdata) if isinstance(self.vdata, (str, os.PathLike)) else np.asarray(self.vdata)
+        if self.vdata is None and self.videos is not None:
+            from .demo_pipeline import build_vdata
+            vdata = build_vdata(self.videos, self.idims, self.nvideos, self.nlen, self.nskip, self.rescale, self.inception,
+                                log=self.log if self.rank == 0 else None)
+            if self.rank == 0:
+                np.save(basedir + "vdata_strike" + str(vdata.shape[1]), vdata)                 # train_script.py:95
+        else:
+            vdata = np.load(self.vdata) if isinstance(self.vdata, (str, os.PathLike)) else np.asarray(self.vdata)
         if vdata.ndim != 5 or vdata.shape[2:4] != self.idims or vdata.shape[0] < self.nlen:
             raise ValueError(f"vdata must be [T >= {self.nlen}, N, {self.idims[0]}, {self.idims[1]}, 3], got {vdata.shape}")
         B, nlen = self.batch_size, self.nlen

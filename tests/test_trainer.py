@@ -203,3 +203,24 @@ class _NoSampler:
         if name in ("load_demos", "train_step_sampled", "eval_sampled"):
             raise AttributeError(name)
         return getattr(self._tr, name)
+
+
+def test_trainer_builds_the_demo_tensor_from_decoded_videos(tmp_path):
+    """ModelTrainer(videos=...): scripts/train_script.py:59-96 on decoded videos (51 frames each, any size) -- frames 1, 1 + nskip, ...
+    resized to idims by the restated scipy.misc.imresize, rescaled, stacked [nlen, nvideos, h, w, 3], saved like :95 -- then the
+    usual loop on the result (device sampler eligible: the tensor lies on the uint8 lattice)."""
+    from imitation_from_observation_amd.demo_pipeline import transform
+    rng = np.random.default_rng(9)
+    videos = [rng.integers(1, 256, (51, 24, 24, 3), dtype=np.uint8) for _ in range(NVID)]
+    nskip = 17                                                    # frames 1, 18, 35 -> nlen = 3
+    base = str(tmp_path / "vid") + "/"
+    np.random.seed(3)
+    lines = []
+    t = ModelTrainer((H, W), NVID, NTRAIN, B, "ContextSkipNew", 9, 8, NLEN, nskip, vdata=None, videos=videos, basedir=base,
+                     translator=OracleModel(3), log=lines.append)
+    t.train()
+    saved = np.load(base + "vdata_strike%d.npy" % NVID)
+    assert saved.shape == (NLEN, NVID, H, W, 3)
+    np.testing.assert_array_equal(saved[1, 2], transform(videos[2][18], H, W, True))
+    assert on_u8_lattice(saved)[1]
+    assert any(ln.endswith("E") for ln in lines)                  # the loop ran to its validation at itr 8
