@@ -758,18 +758,23 @@ __global__ __launch_bounds__(NTHREADS) void adam_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, int64_t n, float lr_t, float b1, float b2,
                                                         float eps) {
     const float c1 = 1.f - b1, c2 = 1.f - b2;
+    // streaming: every element is touched once per step and the arena (0.76 GB) is larger than any cache -- nontemporal loads and
+    // stores (1.334 GB in 0.231 ms = 5.8 TB/s against 0.245 ms with plain accesses; deeper unrolling measured slower, round 4)
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (int64_t i = ((int64_t)blockIdx.x * NTHREADS + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 256 * 4) {
-        const float4 gg = ldg4(g + i);
-        float4 mm = ldg4(m + i), vv = ldg4(v + i), pp = ldg4(p + i);
-#define CTX_ADAM1(f)                                   \
-    mm.f = b1 * mm.f + c1 * gg.f;                      \
-    vv.f = b2 * vv.f + c2 * (gg.f * gg.f);             \
-    pp.f = pp.f - lr_t * mm.f / (sqrtf(vv.f) + eps);
-        CTX_ADAM1(x) CTX_ADAM1(y) CTX_ADAM1(z) CTX_ADAM1(w)
-#undef CTX_ADAM1
-        *reinterpret_cast<float4*>(m + i) = mm;
-        *reinterpret_cast<float4*>(v + i) = vv;
-        *reinterpret_cast<float4*>(p + i) = pp;
+        const f4 gg = __builtin_nontemporal_load(reinterpret_cast<const f4*>(g + i));
+        f4 mm = __builtin_nontemporal_load(reinterpret_cast<const f4*>(m + i));
+        f4 vv = __builtin_nontemporal_load(reinterpret_cast<const f4*>(v + i));
+        f4 pp = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p + i));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = b1 * mm[k] + c1 * gg[k];
+            vv[k] = b2 * vv[k] + c2 * (gg[k] * gg[k]);
+            pp[k] = pp[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        }
+        __builtin_nontemporal_store(mm, reinterpret_cast<f4*>(m + i));
+        __builtin_nontemporal_store(vv, reinterpret_cast<f4*>(v + i));
+        __builtin_nontemporal_store(pp, reinterpret_cast<f4*>(p + i));
     }
 }
 

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  CTX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/p$i -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --kernel-iters 1 --no-split-leg --no-secondary --sustained-s 0 > $O/p$i.log 2>&1
+  CTX_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/p$i -o r -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --kernel-iters 1 --no-split-leg --no-secondary --no-sampled --sustained-s 0 > $O/p$i.log 2>&1
 done
 cd $R
 python - <<PY
