@@ -18,4 +18,8 @@ void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& 
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws) {
     launch_igemm(s, a, b, ep, M, N, 1, a.ntaps() * a.cps, ws);
 }
+void convt1_fwd_q(hipStream_t s, const KmConvT1GatherQ& a, const KmConvT1WeightsQ& b, Epi ep, int N, SplitWs ws) {
+    ep.rowmode = 4; ep.hs = a.g.hs; ep.ws = a.g.ws; ep.xcd_swizzle = xcd_swz() & ws.swz & 1;
+    launch_igemm<KmConvT1GatherQ, KmConvT1WeightsQ, true, 2, 2>(s, a, b, ep, a.nimg, N, a.g.hs * a.g.ws, posgeo_min_chunks(a.g), ws);
+}
 }  // namespace ctx

@@ -1004,6 +1004,53 @@ struct KmConvTWeightsQ {
     __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
 };
 
+// conv2d_transpose, stride 1, position-major: out[n,i,j,a] = sum in[n, i + pad - ky, j + pad - kx, k] * w[ky][kx][a][k].
+// With ky' = K-1-ky this is PosGeo's correlation (s = 1, hb = hs, wb = ws) with pad' = K-1-pad: only the taps inside the grid are
+// chunks (on a 2x2 grid with K 3: 4 of 9; on 1x1: 1 of 9), and the filter tap of chunk (ky', kx') is (K-1-ky', K-1-kx').
+// Two sources as in KmConvTGatherQ (the decoder's concat([d, skip]), the skip indexed by image % nmod2).  Epilogue rowmode 4.
+struct KmConvT1GatherQ {
+    static constexpr bool KM = true;
+    const float* s1; int64_t ld1; int c1;   // c1 a multiple of KC
+    const float* s2; int64_t ld2; int nmod2;
+    PosGeo g;                               // make_posgeo(hs, ws, hs, ws, 1, K - 1 - pad, K, cps)
+    int nimg;
+    const float* zeros;
+    typedef TapPos KPos;
+    typedef PosGeo::Blk KBlock;
+    struct Pos { rsrc_t rs; bool second; };
+    struct Ctx { uint32_t v1, v2; };
+    __device__ int nchunks_of(int prob) const { return g.nchunks(prob); }
+    __device__ KBlock kblock(int prob) const { return g.kblock(prob); }
+    __device__ KPos kpos(const KBlock& b, int chunk) const { return g.kpos(b, chunk); }
+    __device__ Pos pos(int, int, const KPos& t) const {
+        const int64_t d = (int64_t)(t.ky - g.pad) * g.wb + (t.kx - g.pad);
+        const int kc = t.slice * KC;
+        const bool second = kc >= c1;
+        return Pos{make_rsrc(second ? s2 + d * ld2 + (kc - c1) : s1 + d * ld1 + kc), second};
+    }
+    __device__ void prep(int prob, int row, int k4, Ctx& c) const {
+        int i, j;
+        g.where(prob, i, j);
+        const int64_t pix = (int64_t)i * g.wb + j, hw = (int64_t)g.hb * g.wb;
+        c.v1 = row < nimg ? (uint32_t)((row * hw + pix) * ld1 + k4) * 4u : OOB;
+        c.v2 = row < nimg ? (uint32_t)(((row % nmod2) * hw + pix) * ld2 + k4) * 4u : OOB;
+    }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, q.second ? c.v2 : c.v1); }
+};
+// its filter w[ky][kx][a][b] (a = output channel = tile row, b = k) as the B operand
+struct KmConvT1WeightsQ {
+    static constexpr bool KM = true;
+    const float* w; int ca, cb, K;
+    const float* zeros;
+    struct Pos { rsrc_t rs; };
+    struct Ctx { uint32_t v; };
+    __device__ Pos pos(int, int, const TapPos& t) const {
+        return Pos{make_rsrc(w + (int64_t)((K - 1 - t.ky) * K + (K - 1 - t.kx)) * ca * cb + t.slice * KC)};
+    }
+    __device__ void prep(int, int row, int k4, Ctx& c) const { c.v = row < ca ? (uint32_t)(row * cb + k4) * 4u : OOB; }
+    __device__ float4 load(const Ctx& c, const Pos& q) const { return bload4(q.rs, c.v); }
+};
+
 // ------------------------------------------------------------------------------------------------
 // LDS tiles.  NT = threads of the block that cooperate on a tile.
 // ------------------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ void conv_wgrad_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmallP& b, E
 void conv_wgrad2_p(hipStream_t s, const NmWgradBigP& a, const NmWgradSmall2P& b, Epi ep, int M, int N, SplitWs ws);
 // stride-1 conv2d_transpose as a flipped stride-1 correlation (a.flip = 1, b.flip25 = 1); filter rows as B
 void convt1_fwd(hipStream_t s, const KmConvGather& a, const KmConvTWeights& b, Epi ep, int M, int N, SplitWs ws);
+void convt1_fwd_q(hipStream_t s, const KmConvT1GatherQ& a, const KmConvT1WeightsQ& b, Epi ep, int N, SplitWs ws);
 // position-major variants (one problem per output position, rows = images): only the taps that land inside the grid
 void conv_fwd_q(hipStream_t s, const KmConvGatherQ& a, const NmConvWeightsQ& b, Epi ep, int N, SplitWs ws);
 void convt_fwd_q(hipStream_t s, const KmConvTGatherQ& a, const KmConvTWeightsQ& b, Epi ep, int N, SplitWs ws);
