@@ -1197,11 +1197,15 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     }
     if (rc == CTX_OK) rc = h->gen ? gen_alloc(h) : alloc_buffers(h);
     if (rc == CTX_OK) {
+        // -1 = by size: the lanes pay where the launches are long enough to hide a cross-queue hop (measured 11.5 us each; a step has ~25
+        // of them).  On ContextAEInception2's 2x2 maps they gain 0.07 ms of 2.7 alone and LOSE 0.23 ms of 6.85 behind the front end on a
+        // caller's stream, where lane and compute stream came to share a hardware queue (profiles/round4_e_config4_lanes.txt).
+        if (h->opt.v[OPT_OVERLAP] < 0) h->opt.v[OPT_OVERLAP] = !(h->gen && h->H * h->W < 64);
         h->overlap = h->opt.v[OPT_OVERLAP] != 0;
         h->use_graphs = h->opt.v[OPT_GRAPHS] != 0;
         // Side-lane stream priority: NORMAL.  (Lowest was -0.03 ms on the ContextSkipNew step and -0.7 ms on the split-bf16 config-4
         // step, but the f32 config-4 step -- front end chained on the same stream -- went from 7.8 to 17.4 ms with it; highest +0.08 ms.)
-        const int lane_prio = 0;
+        const int lane_prio = h->opt.v[OPT_LANE_PRIO];
         for (int l = 0; l < ctx_handle::NLANE && rc == CTX_OK; ++l)
             if (hipStreamCreateWithPriority(&h->aux[l], hipStreamNonBlocking, lane_prio) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming) != hipSuccess ||

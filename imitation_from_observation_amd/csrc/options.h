@@ -7,7 +7,8 @@
 namespace ctx {
 
 enum Opt {
-    OPT_OVERLAP,       // 1: the step runs on three stream lanes (conv_context chain, filter / bias gradients beside the dx chain); 0: one stream
+    OPT_OVERLAP,       // 1: the step runs on three stream lanes (conv_context chain, filter / bias gradients beside the dx chain); 0: one stream;
+                       // -1 (default): by size at create -- off for the table-driven translators on maps under 64 positions; reads back 0 / 1
     OPT_GRAPHS,        // 1: the inference fetches at B <= 64 and the CNN front end replay captured hipGraphs
     OPT_POSMAJOR,      // 1: position-major convolutions (only the taps inside the grid) at >= 64 images
     OPT_XCD_SWIZZLE,   // bits: 1 position-major conv, 2 position-major transposed conv, 4 rectangle-ordered filter gradient: contiguous runs of work per XCD
@@ -20,6 +21,7 @@ enum Opt {
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
     OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
     OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)
+    OPT_LANE_PRIO,     // HIP priority of the side-lane streams, read at create: 0 normal, -1 high, 1 low (a priority class has its own hardware queues)
     OPT_COUNT
 };
 

@@ -117,7 +117,8 @@ const char* ctx_last_error(const ctx_handle* h);
  * Every switch is an int.  A handle starts from the built-in defaults overridden by the environment variables CTX_<NAME> (upper
  * case) as they stand at ctx_create; ctx_set_option changes it for that handle only (two handles of one process may differ).
  * Names (ctx_option_count / ctx_option_name enumerate them):
- *   overlap      1   the step runs on three stream lanes (conv_context chain; filter / bias gradients beside the dx chain); 0 = one stream
+ *   overlap     -1   1 = the step runs on three stream lanes (conv_context chain; filter / bias gradients beside the dx chain); 0 = one stream;
+ *                    -1 = decided at create (off for the table-driven translators on maps under 64 positions) and reads back as 0 / 1
  *   graphs       1   the inference fetches at B <= 64 replay captured hipGraphs
  *   posmajor     1   position-major convolutions (only the taps inside the grid) from 64 images up
  *   xcd_swizzle  7   bits: contiguous runs of work per XCD for 1 the position-major conv, 2 the transposed conv, 4 the filter gradient
@@ -130,6 +131,7 @@ const char* ctx_last_error(const ctx_handle* h);
  *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create)
  *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create)
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
+ *   lane_prio    0   HIP priority of the side-lane streams (0 normal, -1 high, 1 low); read at create only
  * Results never depend on a switch beyond f32 summation order.  Not options: CTX_RCCL_LIB (path of the librccl to dlopen, read by the
  * first ctx_dp_* call of the process). */
 int ctx_option_count(void);

@@ -10,7 +10,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = []
 for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Stream_Id", r.get("Queue_Id", "?"))))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], str(r.get("Stream_Id", "?")) + "/" + str(r.get("Queue_Id", "?"))))
 rows.sort()
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
 # a step = (after the previous step's last adam launch, through this step's last adam launch)
@@ -29,7 +29,7 @@ ev.sort()
 print(f"step of {len(step)} kernels, {(step[-1][1] - t0) / 1e6:.3f} ms")
 for s, e, n, q in step:
     conc = sum(1 for s2, e2, _, _ in step if s2 < s < e2)
-    print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  q={q:>3} +{conc}  {short(n)}")
+    print(f"{(s - t0) / 1e3:9.1f} {(e - t0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} us  stream/queue={q:>5} +{conc}  {short(n)}")
 hist = {}
 cur = 0; last = ev[0][0]
 for t, dlt in ev:
