@@ -464,10 +464,13 @@ constexpr int LANE_CTX = 0, LANE_DW = 1;
 // a slice may go as soon as (1) its gradients are final and (2) nothing later in this step reads its parameters.  backward() marks
 // those points with adam_early(); adam_end() updates what is left on the compute stream and joins.  The arithmetic per element is
 // that of adam_step (same kernel, same lr_t): results are bit-identical to the unsliced update (tests/test_gpu_parity.py).
-// MEASURED (round 3, six back-to-back bench runs): no gain -- 13.79 / 13.81 ms with the slices against 13.79 / 13.79 without, tail
-// slice only 13.76, encoder slices only 13.83.  The matrix-core kernels it would hide under own the CUs' registers and LDS, so the
-// Adam blocks displace their blocks instead of running beside them: the step costs the sum of the work either way.  OFF unless
-// option "early_adam" is set (ctx_set_option; read at every step).
+// MEASURED: round 3 (six back-to-back bench runs) no gain, 13.79 / 13.81 ms with the slices against 13.79 / 13.79 without.  Round 4, with
+// the nontemporal Adam kernel: -0.06..-0.08 ms in four A/B pairs (13.205 -> 13.134, 13.247 -> 13.167, 13.185 -> 13.124) -- and the kernel
+// trace shows why it is not more: the runtime multiplexes HIP streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, the process's null
+// stream holds one, compute stream and two lanes the other three, and `adam_stream` lands on the filter-gradient lane's queue, so the
+// slices run beside the dx chain but in turn with the filter gradients.  With GPU_MAX_HW_QUEUES=8 it has its own queue and the step
+// loses another 0.05 ms, but ContextAEReal's small launches then run truly side by side and get slower (2.71 -> 3.11 ms), so the
+// library does not ask for it (profiles/round4_e_early_adam_queues.txt).  ON by default (option "early_adam"; read at every step).
 void adam_launch(ctx_handle* h, hipStream_t s, int64_t first, int64_t end) {
     adam(s, h->arena + first, h->arena + h->Ppad + first, h->arena + 2 * h->Ppad + first, h->arena + 3 * h->Ppad + first, end - first,
          h->adam_lr_t, 0.9f, 0.999f, 1e-8f);

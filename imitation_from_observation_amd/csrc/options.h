@@ -17,7 +17,7 @@ enum Opt {
     OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3)
     OPT_DCONV,         // 1: ContextAEReal in f32 on the narrow-channel direct kernels (dconv.h)
     OPT_RCHAIN,        // 1: ContextAEReal's FC middle in three launches (rchain.hip)
-    OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused steps (bit-identical; measured: no gain)
+    OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms, round 4)
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
     OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
     OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)

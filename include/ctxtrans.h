@@ -127,7 +127,7 @@ const char* ctx_last_error(const ctx_handle* h);
  *   direct3     15   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass  [fixed at create]
  *   dconv        1   ContextAEReal in f32 on the narrow-channel direct kernels                                          [fixed at create]
  *   rchain       1   ContextAEReal's FC middle in three launches
- *   early_adam   0   Adam's slices beside the remaining backward in the fused steps (bit-identical; measured: no gain)
+ *   early_adam   1   Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms)
  *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create)
  *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create)
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
@@ -234,8 +234,8 @@ int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const
  * sess.run([..., optim]) without the host copies), enqueued on the handle's stream, no synchronisation.
  * Same result, bit for bit, as ctx_dev_forward_backward(sim_batch = 0) followed by ctx_dev_adam(lr).  With
  * option "early_adam" set, Adam's update of a parameter slice is enqueued beside the remaining
- * backward as soon as that slice's gradients are final and its parameters are no longer read (measured: no
- * gain on MI355X, so off by default; still bit-identical).  The host-fed steps (ctx_train_step, _u8, _sampled)
+ * backward as soon as that slice's gradients are final and its parameters are no longer read (on by default:
+ * -0.06 ms of 13.1 on MI355X; bit-identical either way).  The host-fed steps (ctx_train_step, _u8, _sampled)
  * go through the same code. */
 int ctx_dev_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B,
                        float lr);

@@ -12,9 +12,14 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], str(r.get("Stream_Id", "?")) + "/" + str(r.get("Queue_Id", "?"))))
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
-# a step = (after the previous step's last adam launch, through this step's last adam launch)
-ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 20]
+import os
+cut = os.environ.get("TIMELINE_CUT", "")          # e.g. loss_final_kernel: one per step (then a "step" runs from the backward of one
+if cut:                                            # step through the forward of the next -- needed when Adam runs in slices)
+    ends = [i for i, r in enumerate(rows) if cut in r[2]]
+else:
+    adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+    # a step = (after the previous step's last adam launch, through this step's last adam launch)
+    ends = [i for k, i in enumerate(adam) if k + 1 == len(adam) or adam[k + 1] - i > 20]
 e1 = ends[-back]; e0 = ends[-back - 1]
 step = rows[e0 + 1:e1 + 1]
 t0 = step[0][0]
