@@ -619,6 +619,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
         P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
         dconv_conv(h->stream, P, 2, 1);
     } else if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
+    else if (h->cfg.precision == CTX_PREC_F32 && wconv_ok(hs, ws, ca, cb, nimg, ep)) wconv_fwd(h->stream, x, ca, nimg, hs, ws, w, cb, ep);
     else if (use_q(nimg)) conv_fwd_q(h->stream, KmConvGatherQ{x, ca, make_posgeo(hs, ws, hb, wb, 2, 1, 5, ca / KC), nimg, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ep, cb, ws_of(h));
     else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
@@ -838,7 +839,8 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl, uf);
-              if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
+              if (h->cfg.precision == CTX_PREC_F32 && wconv_ok(hs, wsm, ca, cb, 2 * B, ed)) wconv_fwd(h->stream, dy, ca, 2 * B, hs, wsm, w, cb, ed);
+              else if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
               else conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
         }
         dy = d_dec;

@@ -103,6 +103,9 @@ void c3conv(hipStream_t s, const float* x, int nimg, int hin, int win, int strid
 // conv2d_transpose 5x5 stride 2 for wide channel counts on the 8x8 / 16x16 grids: image-major, input halo tile resident in LDS
 // (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
 bool wconvt_ok(int hs, int ws, int c1, int c2, int ca, int nimg);
+// conv2d 5x5 stride 2 SAME onto a ho x wo grid with the input halo tile resident in LDS (wconv.hip): x [nimg, 2 ho, 2 wo, ci], filter w[5][5][ci][co]
+bool wconv_ok(int ho, int wo, int ci, int co, int nimg, const Epi& ep);
+void wconv_fwd(hipStream_t s, const float* x, int ci, int nimg, int ho, int wo, const float* w, int co, const Epi& ep);
 void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
                 const Epi& ep, SplitWs ws_);
 

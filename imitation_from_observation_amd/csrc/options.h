@@ -21,6 +21,8 @@ enum Opt {
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
     OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
     OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)
+    OPT_WCONV,         // 1: stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills
+                       // the chip, 2: whatever its size; 0 (default): position-major implicit GEMM.  Measured: 2-4 % faster alone, step +0.05 ms
     OPT_LANE_PRIO,     // HIP priority of the side-lane streams, read at create: 0 normal, -1 high, 1 low (a priority class has its own hardware queues)
     OPT_COUNT
 };
