@@ -40,6 +40,7 @@ struct ctx_cnn {
     static constexpr int NLANE = 4;                   // branch lanes: lane 0 is `stream`
     hipStream_t lane[NLANE] = {};
     float* slab[NLANE] = {};                          // one split-K workspace per lane
+    float* wpack[NLANE] = {};                         // dconv's re-packed filter, per lane
     int64_t slab_floats = 0;
     std::vector<hipEvent_t> done;                     // done[i]: op i finished (recorded on its lane)
     std::vector<std::vector<int>> deps;               // deps[i]: ops on OTHER lanes that write op i's src buffer
@@ -175,6 +176,15 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
                 NmC3Weights b{w, op.cout, h->zeros};
                 b.ntap = op.kh * op.kw; b.cs = in.c;
                 conv3_fwd(st, a, b, ep, R, op.cout, ws);
+            } else if (h->precision == CTX_PREC_F32 && opt(OPT_CNN_DCONV) && op.kh == op.kw && cin >= 8 && (cin & (cin - 1)) == 0 && dconv_ok(cin, op.cout) &&
+                       (opt(OPT_CNN_DCONV) >= 2 || (cin <= 32 && op.cout <= 32))) {
+                // Conv2d_2a_3x3 (32 -> 32): a 32-column GEMM wastes the implicit GEMM's tiles (57 TF/s); the direct convolution over an LDS
+                // halo tile with the filter resident (dconv.h) runs it at 81 (0.223 -> 0.157 ms at 192 images of 125x125).  Wider layers lose:
+                // 32 -> 64 0.271 -> 0.399 ms, 64 -> 80 1x1 0.076 -> 0.125, 64 -> 96 0.048 -> 0.092 (option value 2 runs them all)
+                DcFwd D{};
+                D.x1 = x; D.ld1 = in.c; D.c1 = cin; D.CI = cin; D.hin = in.h; D.win = in.w; D.nimg = n;
+                D.w = w; D.wmode = 0; D.N = op.cout; D.ep = ep; D.wp = h->wpack[L];
+                dconv_conv_k(st, D, op.kh, op.kw, op.stride, pady, padx, out.h, out.w);
             } else if (n >= 64 && op.same && op.kh * op.kw > 1) {   // position-major: SAME-padding taps outside the grid are never multiplied
                 PosGeo g = make_posgeo(out.h, out.w, in.h, in.w, op.stride, pady, op.kh, cin / KC);
                 g.KW = op.kw; g.padx = padx;
@@ -261,6 +271,7 @@ int ctx_cnn_create(const ctx_cnn_buf* bufs, int nbufs, const ctx_cnn_op* ops, in
     h->lane[0] = h->stream;
     for (int l = 0; l < ctx_cnn::NLANE; ++l) {
         alloc((void**)&h->slab[l], (size_t)h->slab_floats * sizeof(float), false);
+        alloc((void**)&h->wpack[l], (size_t)DC_WPACK_FLOATS * sizeof(float), false);
         if (l && ok) ok = hipStreamCreateWithFlags(&h->lane[l], hipStreamNonBlocking) == hipSuccess;
     }
     h->done.assign(nops, nullptr);
@@ -288,6 +299,7 @@ void ctx_cnn_destroy(ctx_cnn* h) {
     for (void* p : {(void*)h->weights, (void*)h->u8, (void*)h->f32in, (void*)h->zeros}) if (p) (void)hipFree(p);
     for (int l = 0; l < ctx_cnn::NLANE; ++l) {
         if (h->slab[l]) (void)hipFree(h->slab[l]);
+        if (h->wpack[l]) (void)hipFree(h->wpack[l]);
         if (l && h->lane[l]) { (void)hipStreamSynchronize(h->lane[l]); (void)hipStreamDestroy(h->lane[l]); }
     }
     for (auto& kv : h->graphs) if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);

@@ -175,6 +175,18 @@ void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad) {
     dconv_launch(s, P, 5);
 }
 
+// conv2d kh x kw (<= 25 taps, kh, kw <= 7), stride s, pad_before (pady, padx), output grid hout x wout given (SAME or VALID): the
+// Inception front end's narrow stem layers (nets/inception_v3.py:101-116: 3x3 32->32 VALID, 3x3 32->64 SAME, 1x1 64->80).  w[tap][k][n].
+void dconv_conv_k(hipStream_t s, DcFwd P, int kh, int kw, int stride, int pady, int padx, int hout, int wout) {
+    P.S = stride; P.y_org = -pady; P.x_org = -padx;
+    P.hlog = P.hout = hout; P.wlog = P.wout = wout; P.osc = 1;
+    const int mdiv = kw == 1 ? 256 : kw == 2 ? 128 : kw == 3 ? 86 : kw == 4 ? 64 : kw == 5 ? 52 : kw == 6 ? 43 : 37;
+    P.ncls = 1; P.cls[0] = DcClass{0, kh * kw, 0, 0, 0, kw, mdiv, 0, 0, 1};
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx) P.taps[ky * kw + kx] = DcTap{(int16_t)ky, (int16_t)kx, (int16_t)(ky * kw + kx), 0};
+    dconv_launch(s, P, kh > kw ? kh : kw);
+}
+
 // conv2d_transpose 5x5 stride 1 (SAME pad 2): out[q] = sum_taps in[q + 2 - tap] * w[tap]  -- a correlation with the mirrored offsets
 void dconv_convt1(hipStream_t s, DcFwd P) {
     P.S = 1; P.y_org = -2; P.x_org = -2;

@@ -76,6 +76,7 @@ void conv3_wgrad2(hipStream_t s, const NmC3WgradBig& a, const NmWgradSmall2& b, 
 bool dconv_ok(int CI, int N);
 constexpr int64_t DC_WPACK_FLOATS = 40ll * 64 * 128 + 64;   // P.wp: <= 37 class-padded tap slots x 64 k x 128 n, then their tile offsets
 void dconv_conv(hipStream_t s, DcFwd P, int stride, int pad);        // conv2d 5x5 SAME (also: input gradient of conv2d_transpose)
+void dconv_conv_k(hipStream_t s, DcFwd P, int kh, int kw, int stride, int pady, int padx, int hout, int wout);   // conv2d kh x kw, given output grid (SAME or VALID)
 void dconv_convt1(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 1 (also: input gradient of a stride-1 conv2d)
 void dconv_convt2(hipStream_t s, DcFwd P);                           // conv2d_transpose 5x5 stride 2 (also: input gradient of a stride-2 conv2d)
 void dconv_wgrad(hipStream_t s, DcWgrad P, float* slab, int64_t slab_floats);   // filter gradient of either, 25 taps in one launch

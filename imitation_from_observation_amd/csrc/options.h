@@ -19,6 +19,8 @@ enum Opt {
     OPT_RCHAIN,        // 1: ContextAEReal's FC middle in three launches (rchain.hip)
     OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms, round 4)
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
+    OPT_CNN_DCONV,     // Inception front end, f32: 1 = layers of <= 32 input and output channels (Conv2d_2a_3x3) on the direct kernels of dconv.h;
+                       // 2 = every layer they are instantiated for (measured slower); 0 = implicit GEMM
     OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
     OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)
     OPT_WCONV,         // 1: stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills

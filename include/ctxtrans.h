@@ -129,6 +129,7 @@ const char* ctx_last_error(const ctx_handle* h);
  *   rchain       1   ContextAEReal's FC middle in three launches
  *   early_adam   1   Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms)
  *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create)
+ *   cnn_dconv    1   Inception front end (f32): layers of <= 32 input and output channels on the direct kernels (dconv.h); 2 = every eligible layer
  *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create)
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
  *   wconv        0   1 = stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills the
