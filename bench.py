@@ -573,6 +573,23 @@ def main():
             "ridge_flop_per_byte": PEAK_F32_MFMA / PEAK_HBM,
         },
     }
+    if rank == 0 and not args.no_secondary:
+        # "confirm on the box with a copy kernel and an FMA loop and report measured peaks too".  tools/libpeaks.so (built by
+        # __graft_entry__.build(), not part of the product): an f32 matrix-core loop and a stream copy, outside the timed region.
+        try:
+            import ctypes
+            pk = ctypes.CDLL(os.path.join(ROOT, "tools", "libpeaks.so"))
+            pk.peak_mfma_f32_tflops.restype = ctypes.c_double
+            pk.peak_hbm_copy_gbps.restype = ctypes.c_double
+            pk.peak_hbm_copy_gbps.argtypes = [ctypes.c_int64]
+            mf, cp = pk.peak_mfma_f32_tflops(), pk.peak_hbm_copy_gbps(1 << 30)
+            line["peaks_measured"] = {
+                "mfma_f32_tflops": mf, "hbm_copy_GBps": cp,
+                "note": "v_mfma_f32_32x32x2_f32 loop on 8 waves per CU; 1 GiB device-to-device copy (read + write); nominal 157.3 TF/s, 8 TB/s",
+                "step_frac_of_measured_mfma": (line["step_rates"]["tflops_f32"] / mf) if mf > 0 else None,
+                "step_useful_frac_of_measured_mfma": (line["step_rates"]["tflops_useful"] / mf) if mf > 0 else None}
+        except OSError:
+            line["peaks_measured"] = None
     if dist.is_initialized():
         # Outside the timed region: what one step spends in compute and what the gradient all-reduce costs alone, so that the
         # per-N values can be read (exposed communication = ms_per_step - compute_ms; an overlapped schedule can hide at most

@@ -87,6 +87,36 @@ def test_forward_backward_matches_oracle(T, H, W, d, F, B):
         np.testing.assert_array_equal(tr.get_params_flat(), o.flatten(p, cfg, np.float32))   # lr 0 => unchanged
 
 
+@pytest.mark.parametrize("H,W,d,F,B", [(32, 32, 32, 128, 4), (64, 64, 32, 64, 3), (16, 16, 32, 32, 64)])
+def test_smooth_frames_match_oracle(T, H, W, d, F, B):
+    """SURVEY 8(d)'s second input distribution: low-frequency blobs (tests/_frames.py), which mimic rendered frames -- coherent conv
+    outputs, flat regions on one lrelu branch -- through the uint8 inference fetch and the training step, same bars as on noise
+    (outputs 1e-5, gradients 1e-4 of each tensor's max with the oracle on the device's lrelu' branches)."""
+    from tests._align import align_skipnew_cache
+    from tests._frames import blob_frames
+    cfg, p, _ = make_case(H, W, d, F, B, seed=3)
+    rng = np.random.default_rng(33)
+    fr = [blob_frames(rng, B, H, W) for _ in range(3)]
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    res, c = o.forward(p, *(x.astype(np.float64) for x in (src, ctx, tgt)), cfg)
+    with T(H, W, d, F, max_batch=B) as tr:
+        tr.set_params(p)
+        pred, feat = tr.translate(fr[0], fr[1][0])                                       # the reward hook's fetch on uint8 frames
+        opred, ofeat = o.translate(p, fr[0], fr[1][0], cfg)
+        assert relmax(pred, opred) < 1e-5 and relmax(feat, ofeat) < 1e-5
+        ev = tr.evaluate(src, ctx, tgt)
+        assert relmax(ev["out"], res["out"]) < 1e-5 and relmax(ev["out2"], res["out2"]) < 1e-5
+        for k in ("loss", "simloss", "recon1", "recon2"):
+            assert abs(ev[k] - res[k]) <= 1e-5 * abs(res[k]) + 1e-6, k
+        nflip, worst = align_skipnew_cache(tr, c, B)
+        assert worst < 1e-5
+        g = o.backward(p, c, cfg)
+        tr.train_step(src, ctx, tgt, lr=0.0)
+        gg = tr.get_grads()
+        for n in g:
+            assert relmax(gg[n], g[n]) < 1e-4, (n, nflip)
+
+
 @pytest.mark.parametrize("H,W,d,F,B", [(16, 16, 32, 32, 64), (32, 16, 32, 64, 32), (16, 32, 32, 32, 96)])
 def test_position_major_launches_match_oracle(T, H, W, d, F, B):
     """Batches of >= 64 images per launch take the position-major conv / transposed-conv kernels (one problem per output

@@ -153,6 +153,27 @@ def test_oracle_matches_independent_torch_autograd(H, W, d, F, B):
         assert np.abs(g[k] - tg[k]).max() <= 1e-9 * scale, k
 
 
+def test_oracle_matches_torch_autograd_on_smooth_frames():
+    """SURVEY 8(d)'s second input distribution (tests/_frames.py: low-frequency blobs, uint8-quantised, through the inference
+    preprocessing): the two independent statements of the arithmetic agree on it as on noise."""
+    from tests._frames import blob_frames
+    H, W, d, F, B = 32, 32, 8, 16, 3
+    cfg = o.SkipNewConfig(H=H, W=W, df_dim=d, gf_dim=d, featsize=F)
+    p = o.init_params(cfg, 9, np.float64, stddev=0.2)
+    rng = np.random.default_rng(21)
+    src, ctx, tgt = (o.preprocess_u8(blob_frames(rng, B, H, W)).astype(np.float64) for _ in range(3))
+    assert np.abs(np.diff(src, axis=2)).mean() < 0.1            # smooth: neighbours differ by a few grey levels (noise: 0.67)
+    res, c = o.forward(p, src, ctx, tgt, cfg)
+    g = o.backward(p, c, cfg)
+    tres, tg = _torch_grads(cfg, p, src, ctx, tgt)
+    for k in ["input_z", "translated_z", "out", "out2"]:
+        np.testing.assert_allclose(res[k], tres[k].detach().numpy(), rtol=1e-9, atol=1e-11)
+    for k in ["simloss", "recon1", "recon2", "loss"]:
+        assert abs(res[k] - float(tres[k])) <= 1e-10 * abs(float(tres[k]))
+    for k in g:
+        assert np.abs(g[k] - tg[k]).max() <= 1e-9 * (np.abs(tg[k]).max() + 1e-30), k
+
+
 def test_finite_difference_gradient():
     cfg = o.SkipNewConfig(H=16, W=16, df_dim=4, gf_dim=4, featsize=8)
     p = o.init_params(cfg, 7, np.float64, stddev=0.2)
