@@ -113,29 +113,32 @@ def secondary_legs(device, steps=40):
     import torch
     from imitation_from_observation_amd import Translator
     out = {}
-    try:
-        Hh, Ww, Bb = 36, 64, 256
-        tr = Translator(Hh, Ww, featsize=100, max_batch=Bb, variant="real", device=device)
-        tr.init_params(0)
-        g = torch.Generator(device="cuda").manual_seed(7)
-        d = [(torch.randint(0, 256, (Bb, Hh, Ww, 3), device="cuda", generator=g, dtype=torch.uint8).float() / 127.5 - 1.0).contiguous()
-             for _ in range(3)]
-        torch.cuda.synchronize()
-        for _ in range(5):
-            tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
-        tr.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
-        tr.sync()
-        dt = (time.perf_counter() - t0) / steps
-        fl = real_flops_per_triple(Hh, Ww) * Bb
-        out["context_ae_real_36x64_b256"] = {"ms_per_step": 1e3 * dt, "frames_per_s": Bb / dt, "steps": steps,
-                                             "gflop_per_step": fl / 1e9, "tflops": fl / dt / 1e12,
-                                             "frac_f32_mfma_peak": fl / dt / PEAK_F32_MFMA, "loss_after": tr.dev_scalars()["loss"]}
-        tr.close()
-    except Exception as e:                                   # a secondary leg must never cost the bench line
-        out["context_ae_real_36x64_b256"] = {"error": repr(e)[:300]}
+    for Hh, Ww, Bb in ((36, 64, 256), (64, 64, 256)):          # the reference's sweep size (base.py:134-135) and BASELINE configs[4]'s 64x64
+        key = f"context_ae_real_{Hh}x{Ww}_b{Bb}"
+        try:
+            tr = Translator(Hh, Ww, featsize=100, max_batch=Bb, variant="real", device=device)
+            tr.init_params(0)
+            g = torch.Generator(device="cuda").manual_seed(7)
+            d = [(torch.randint(0, 256, (Bb, Hh, Ww, 3), device="cuda", generator=g, dtype=torch.uint8).float() / 127.5 - 1.0).contiguous()
+                 for _ in range(3)]
+            torch.cuda.synchronize()
+            for _ in range(5):
+                tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
+            tr.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
+            tr.sync()
+            dt = (time.perf_counter() - t0) / steps
+            fl = real_flops_per_triple(Hh, Ww) * Bb
+            out[key] = {"ms_per_step": 1e3 * dt, "frames_per_s": Bb / dt, "steps": steps, "gflop_per_step": fl / 1e9, "tflops": fl / dt / 1e12,
+                        "frac_f32_mfma_peak": fl / dt / PEAK_F32_MFMA, "loss_after": tr.dev_scalars()["loss"],
+                        "roofline": {"bound": "mfma", "achieved": fl / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                                     "frac": fl / dt / PEAK_F32_MFMA, "traffic": None,
+                                     "note": "whole step on the layers' FLOPs (channels as the reference defines them: 32/16/16/8, no padding)"}}
+            tr.close()
+        except Exception as e:                                   # a secondary leg must never cost the bench line
+            out[key] = {"error": repr(e)[:300]}
     try:
         from imitation_from_observation_amd.inception_frontend import InceptionFrontend
         S, Bc = 125, 64
@@ -174,6 +177,12 @@ def secondary_legs(device, steps=40):
             "frontend_ms": 1e3 * tf_, "frontend_images_per_s": 3 * Bc / tf_, "frontend_gflop_per_image": lay / 1e9,
             "frontend_tflops": lay * 3 * Bc / tf_ / 1e12, "frontend_frac_f32_mfma_peak": lay * 3 * Bc / tf_ / PEAK_F32_MFMA,
             "translator_ms": 1e3 * (dt - tf_), "loss_after": tr.dev_scalars()["loss"],
+            "roofline_frontend": {"bound": "mfma", "achieved": lay * 3 * Bc / tf_ / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+                                  "frac": lay * 3 * Bc / tf_ / PEAK_F32_MFMA, "traffic": None},
+            # the translator's share at 64 triples of 2x2 maps is parameter traffic: 10 touches of every parameter per step (SURVEY 8d:
+            # forward read, backward read, gradient write, Adam's 4 reads and 3 writes)
+            "roofline_translator": {"bound": "hbm", "achieved": tr.n_params * 40.0 / (dt - tf_) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                    "frac": tr.n_params * 40.0 / (dt - tf_) / PEAK_HBM, "traffic": None, "parameters": tr.n_params},
             "note": "synthetic Inception-v3 variables (the checkpoint is not in the reference tree), f32"}
         tr.close()
         front.close()
