@@ -268,8 +268,13 @@ void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int 
     if (stride == 1) {
         launch_ct3<1, 3, 384>(s, A, TW);      // rows per tile = 384 / TW * 3: 18 at TW 64 (36 x 64 frames: two tiles), 36 at TW 32
     } else {
-        if (TW == 64) launch_ct3<2, 2, 256>(s, A, TW);                                 // 8 small-grid rows
-        else launch_ct3<2, 2, 256>(s, A, TW);                                          // TW 32: 16 rows (a 32 x 32 grid in two tiles); TW 16: 32
+        // tiles of 256 / TW * 2 small-grid rows: 8 at TW 64, 16 at TW 32 (a 32 x 32 grid in two tiles), 32 at TW 16.  A STARVED launch -- the
+        // reward hook's batch of 25: 50 tiles for 256 CUs, each walking all 16 channel slices alone, 63 us of a 0.8 ms translate call --
+        // takes quarter-height tiles of two waves instead (200 tiles)
+        const int tr_big = 256 / TW * 2;
+        const int64_t tiles_big = (int64_t)nimg * ((hin + tr_big - 1) / tr_big) * ((win + TW - 1) / TW);
+        if (tiles_big * 2 <= dev_info().cus && hin >= 128 / TW) launch_ct3<2, 1, 128>(s, A, TW);
+        else launch_ct3<2, 2, 256>(s, A, TW);
     }
 }
 

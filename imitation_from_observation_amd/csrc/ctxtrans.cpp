@@ -430,7 +430,9 @@ struct LaneSwap {
     }
     ~LaneSwap() { h->stream = s0; h->slab = sl0; h->scratch = sc0; h->wpack = wp0; }
 };
-bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux[0] && !h->prof_on && !h->capturing; }
+// (inside a graph capture the lanes are captured as branches -- fork / join are event record + wait, which stream capture follows --
+// when option graph_lanes is set: the two encoders of a translate call at batch 25 then run side by side)
+bool use_lanes(const ctx_handle* h) { return h->overlap && h->aux[0] && !h->prof_on && (!h->capturing || h->opt.v[OPT_GRAPH_LANES]); }
 // fork: `lane` starts after everything enqueued so far on the CURRENT stream; join: the current stream
 // continues after everything enqueued so far on `lane`
 void fork(ctx_handle* h, int lane) {
@@ -968,7 +970,7 @@ int forward_inference(ctx_handle* h, int B, Mode mode) {
     if (g.calls++ == 0) { forward(h, B, mode); return CTX_OK; }      // first call: plain (code objects, LDS limits)
     if (!g.exec) {
         hipGraph_t graph = nullptr;
-        h->capturing = true;                                         // single stream inside the capture
+        h->capturing = true;                                         // (lanes inside the capture: option graph_lanes)
         hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             forward(h, B, mode);

@@ -10,6 +10,7 @@ enum Opt {
     OPT_OVERLAP,       // 1: the step runs on three stream lanes (conv_context chain, filter / bias gradients beside the dx chain); 0: one stream;
                        // -1 (default): by size at create -- off for the table-driven translators on maps under 64 positions; reads back 0 / 1
     OPT_GRAPHS,        // 1: the inference fetches at B <= 64 and the CNN front end replay captured hipGraphs
+    OPT_GRAPH_LANES,   // 1: the captured inference forward keeps the stream lanes as graph branches (translate: both encoders side by side)
     OPT_POSMAJOR,      // 1: position-major convolutions (only the taps inside the grid) at >= 64 images
     OPT_XCD_SWIZZLE,   // bits: 1 position-major conv, 2 position-major transposed conv, 4 rectangle-ordered filter gradient: contiguous runs of work per XCD
     OPT_BALANCE,       // bits: 1 load-balanced problem order on <= 16-position grids, 2 on larger grids, 4 for the filter gradient's taps

@@ -603,11 +603,12 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
     const int slots400 = dev_info().cus * 2 * 25 / 32;                     // ~ 78 % of the resident block slots (400 of 512 on MI355X)
     // STARVED launches (the reward hook's batch of 25: d_h1 offers 16-32 blocks to 256 CUs and each walks 32 slices x 25 taps alone --
     // 0.45 ms of a 1.4 ms translate call, profiles/round4_b_reward_trace_before.txt): 32-wide column tiles and the channel slices over
-    // up to 8 blocks, whatever the grid.
+    // up to 16 blocks, whatever the grid.
     const bool starved = ntile * (ca / 64) * 2 <= dev_info().cus;
     if (starved) {
         nb2 = false;
-        while (ks < 8 && ntile * (ca / 32) * ks < dev_info().cus && nsl / (2 * ks) >= 2 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
+        // (up to two blocks per CU: a block's tap steps are latency-bound -- 1.2-1.3 us each at one block per CU -- and a second block hides them)
+        while (ks < 16 && ntile * (ca / 32) * ks < 2 * dev_info().cus && nsl / (2 * ks) >= 2 && wsp.slab && 2 * ks * npix * ca <= wsp.slab_floats) ks *= 2;
     }
     // row blocks (above): option "wconvt" bit 2 = the 4x4 grids, bit 4 = the 8x8 grids, bit 8 = column-uniform waves on the 4x4 grids
     const int wopt = opt(OPT_WCONVT);

@@ -120,6 +120,7 @@ const char* ctx_last_error(const ctx_handle* h);
  *   overlap     -1   1 = the step runs on three stream lanes (conv_context chain; filter / bias gradients beside the dx chain); 0 = one stream;
  *                    -1 = decided at create (off for the table-driven translators on maps under 64 positions) and reads back as 0 / 1
  *   graphs       1   the inference fetches at B <= 64 replay captured hipGraphs
+ *   graph_lanes  1   ... with the stream lanes captured as graph branches (translate: the two encoders run side by side)
  *   posmajor     1   position-major convolutions (only the taps inside the grid) from 64 images up
  *   xcd_swizzle  7   bits: contiguous runs of work per XCD for 1 the position-major conv, 2 the transposed conv, 4 the filter gradient
  *   balance      3   bits: load-balanced problem order 1 on grids of <= 16 positions, 2 on larger grids, 4 for the filter gradient's taps
