@@ -329,6 +329,36 @@ def test_full_size_small_batch_matches_oracle(T):
             assert relmax(gg[n], g[n]) < 2e-4, n                     # both sides are fp32 here
 
 
+def test_reward_fetches_at_production_width_and_batch_25(T):
+    """The reward hook's two fetches at the sizes the reference calls them with (rllab/sampler/base.py:216-218, 234-235: 25 frames of
+    64x64 through the 47.6 M-parameter net): the first call runs plain launches, the second is captured into a hipGraph, later ones
+    replay it -- all three must return the same bits; so must the capture with and without the stream lanes as graph branches
+    (option graph_lanes), where the starved decoder launches take their split / small-tile forms.  Rows of a translate call are
+    independent given the context frame, so the float32 oracle checks rows 0-1 (it takes seconds per row at this width)."""
+    cfg = o.SkipNewConfig()
+    p = o.init_params(cfg, 77, np.float32)
+    rng = np.random.default_rng(12)
+    fr = rng.integers(0, 256, (25, 64, 64, 3), dtype=np.uint8)
+    ctx0 = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    res = {}
+    for lanes in (1, 0):
+        with T(max_batch=25) as tr:
+            tr.set_option("graph_lanes", lanes)
+            tr.set_params(p)
+            calls = [tr.translate(fr, ctx0) for _ in range(4)]
+            enc = [tr.encode(fr) for _ in range(4)]
+            for (pr, ft), (ef, ex) in zip(calls[1:], enc[1:]):
+                np.testing.assert_array_equal(pr, calls[0][0]); np.testing.assert_array_equal(ft, calls[0][1])
+                np.testing.assert_array_equal(ef, enc[0][0]); np.testing.assert_array_equal(ex, enc[0][1])
+            res[lanes] = (calls[0][0].copy(), calls[0][1].copy(), enc[0][0].copy())
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, b)
+    opred, ofeat = o.translate(p, fr[:2], ctx0, cfg)
+    assert relmax(res[1][0][:2], opred) < 1e-4 and relmax(res[1][1][:2], ofeat) < 1e-4
+    of, _ = o.encode(p, fr[:2], cfg)
+    assert relmax(res[1][2][:2], of) < 1e-4
+
+
 # ------------------------------------------------------------------------------- host / boundary behaviour
 def test_checkpoint_roundtrip_and_tf_scope_prefix(T, tmp_path):
     H, W, d, F, B = 16, 16, 32, 32, 2
