@@ -1219,7 +1219,11 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
                 hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
                 rc = fail(h, CTX_E_DEVICE, "side-lane stream/event creation failed");
     }
-    if (rc == CTX_OK && (hipStreamCreateWithFlags(&h->adam_stream, hipStreamNonBlocking) != hipSuccess ||
+    // The Adam stream in its own PRIORITY class (option adam_prio, default 1 = low): a priority class has its own hardware queues, so the
+    // slices of the early update no longer take turns with the filter-gradient lane on a shared queue (step -0.03..-0.05 ms in two A/B
+    // pairs, profiles/round4_e_early_adam_queues.txt).  Its launches are 80-230 us HBM-bound kernels: the slowdown seen with prioritised
+    // LANES (5 us kernels beside another class's) does not apply.
+    if (rc == CTX_OK && (hipStreamCreateWithPriority(&h->adam_stream, hipStreamNonBlocking, h->opt.v[OPT_ADAM_PRIO]) != hipSuccess ||
                          hipEventCreateWithFlags(&h->adam_ev[0], hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&h->adam_ev[1], hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&h->adam_ev_done, hipEventDisableTiming) != hipSuccess))
