@@ -1219,10 +1219,12 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
                 hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) != hipSuccess)
                 rc = fail(h, CTX_E_DEVICE, "side-lane stream/event creation failed");
     }
-    // The Adam stream in its own PRIORITY class (option adam_prio, default 1 = low): a priority class has its own hardware queues, so the
+    // The Adam stream in its own PRIORITY class (option adam_prio, default 2 = low for exact-f32 handles, normal for split-bf16 ones, whose
+    // step -- in a process that also holds an f32 handle -- went from 8.0 to 9.2 ms with it: which streams share a queue is the runtime's choice): a priority class has its own hardware queues, so the
     // slices of the early update no longer take turns with the filter-gradient lane on a shared queue (step -0.03..-0.05 ms in two A/B
     // pairs, profiles/round4_e_early_adam_queues.txt).  Its launches are 80-230 us HBM-bound kernels: the slowdown seen with prioritised
     // LANES (5 us kernels beside another class's) does not apply.
+    if (h->opt.v[OPT_ADAM_PRIO] == 2) h->opt.v[OPT_ADAM_PRIO] = h->cfg.precision == CTX_PREC_F32 ? 1 : 0;     // (2 = by precision; reads back resolved)
     if (rc == CTX_OK && (hipStreamCreateWithPriority(&h->adam_stream, hipStreamNonBlocking, h->opt.v[OPT_ADAM_PRIO]) != hipSuccess ||
                          hipEventCreateWithFlags(&h->adam_ev[0], hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&h->adam_ev[1], hipEventDisableTiming) != hipSuccess ||

@@ -48,7 +48,7 @@ namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 15}, {"direct3", 15}, {"dconv", 1},
-    {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"wconv", 0}, {"lane_prio", 0}, {"adam_prio", 1},
+    {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"wconv", 0}, {"lane_prio", 0}, {"adam_prio", 2},
 };
 }  // namespace
 thread_local const Options* g_opt = nullptr;

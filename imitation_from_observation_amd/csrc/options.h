@@ -27,7 +27,8 @@ enum Opt {
     OPT_WCONV,         // 1: stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills
                        // the chip, 2: whatever its size; 0 (default): position-major implicit GEMM.  Measured: 2-4 % faster alone, step +0.05 ms
     OPT_LANE_PRIO,     // HIP priority of the side-lane streams, read at create: 0 normal, -1 high, 1 low (a priority class has its own hardware queues)
-    OPT_ADAM_PRIO,     // HIP priority of the early-Adam stream, read at create: 1 low (default: its own hardware queue), 0 normal, -1 high
+    OPT_ADAM_PRIO,     // HIP priority of the early-Adam stream, read at create: 1 low (its own hardware queue), 0 normal, -1 high; 2 (default) = 1 for
+                       // exact-f32 handles, 0 for split-bf16 ones; reads back resolved
     OPT_COUNT
 };
 

@@ -136,7 +136,8 @@ const char* ctx_last_error(const ctx_handle* h);
  *   wconv        0   1 = stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills the
  *                    chip, 2 = at any size; 0 = position-major implicit GEMM (2-4 % slower alone, the whole step 0.05 ms faster)
  *   lane_prio    0   HIP priority of the side-lane streams (0 normal, -1 high, 1 low); read at create only
- *   adam_prio    1   HIP priority of the early-Adam stream (1 low: its own hardware queue; 0 normal; -1 high); read at create only
+ *   adam_prio    2   HIP priority of the early-Adam stream (1 low: its own hardware queue; 0 normal; -1 high; 2 = low for exact-f32 handles,
+ *                    normal for split-bf16 ones, reads back resolved); read at create only
  * Results never depend on a switch beyond f32 summation order.  Not options: CTX_RCCL_LIB (path of the librccl to dlopen, read by the
  * first ctx_dp_* call of the process). */
 int ctx_option_count(void);
