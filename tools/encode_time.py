@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imitation_from_observation_amd import Translator
 tr=Translator(max_batch=250); tr.init_params(0)

@@ -1,5 +1,5 @@
-import sys, time, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imitation_from_observation_amd.inception_frontend import InceptionFrontend
 S=125; N=192
 x=(torch.rand((N,S,S,3),device='cuda')*2-1)

@@ -1,6 +1,6 @@
 """Development tool: per-launch table of one ContextAEInception2 training step (config 4's translator: 2x2x2048 feature maps, B = 64)."""
-import sys, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imitation_from_observation_amd import Translator
 B, h, w, c = 64, 2, 2, 2048
 g = torch.Generator(device="cuda").manual_seed(0)

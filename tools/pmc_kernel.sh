@@ -1,6 +1,6 @@
 # PMC passes (kernel-trace only alongside) over one bench step, summarised for the kernels whose name matches the regex $1.
 #   gpurun -- 'bash tools/pmc_kernel.sh wconvt_kernel r3e'
-#   PMC_CMD="python /root/repo/tools/real_step_loop.py" bash tools/pmc_kernel.sh "dconv_fwd|dconv_wgrad|convt3|c3conv|c3wgrad" r4real     (another workload)
+#   PMC_CMD="python $PWD/tools/real_step_loop.py" bash tools/pmc_kernel.sh "dconv_fwd|dconv_wgrad|convt3|c3conv|c3wgrad" r4real     (another workload)
 set -x
 PAT=${1:-wconvt_kernel}; TAG=${2:-x}
 R=$PWD; O=$R/gpurun_out/$TAG/pmc_$(echo $PAT | tr -c "A-Za-z0-9_\n" "_"); mkdir -p $O

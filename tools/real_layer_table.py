@@ -1,5 +1,5 @@
-import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imitation_from_observation_amd import Translator
 B=256
 g=torch.Generator(device="cuda").manual_seed(0)
