@@ -582,7 +582,7 @@ def main():
             "ridge_flop_per_byte": PEAK_F32_MFMA / PEAK_HBM,
         },
     }
-    if rank == 0 and not args.no_secondary:
+    if rank == 0 and world == 1 and not args.no_secondary:
         # "confirm on the box with a copy kernel and an FMA loop and report measured peaks too".  tools/libpeaks.so (built by
         # __graft_entry__.build(), not part of the product): an f32 matrix-core loop and a stream copy, outside the timed region.
         try:
