@@ -37,7 +37,8 @@ def align_skipnew_cache(tr, c, B):
 def align_gen_cache(tr, c, B):
     """The same for the table-driven models (ContextAEInception2 / ContextAEReal without channel padding): device buffers a0..a3 hold
     the conv outputs of the stacked [tgt | src | ctx] images, a4 = h4, Z = [trans_z | tgt_z | src_z | ctx_z], dz / e1..e3 both decoder
-    passes (ctx_debug_read's names for these variants).  c: cache of oracle/ctx_oracle_incep.forward (or ctx_oracle_real.forward)."""
+    passes (ctx_debug_read's names for these variants).  c: cache of oracle/ctx_oracle_incep.forward (or ctx_oracle_real.forward).
+    The code-wide buffers (a4, th0, Z) are kept at a row stride of featsize rounded up to 32 (ContextAEReal: 100 -> 128)."""
     cache_of = {}
     for k in range(5):
         cache_of[f"a{k}"] = [(c["e_tgt"][k], slice(0, B)), (c["e_src"][k], slice(B, 2 * B)), (c["e_ctx"][k], slice(2 * B, 3 * B))]
@@ -50,7 +51,11 @@ def align_gen_cache(tr, c, B):
     for name, parts in cache_of.items():
         rows = max(sl.stop for _, sl in parts)
         per_row = int(np.prod(parts[0][0].shape[1:]))
-        got = tr.debug_read(name, rows * per_row).reshape((rows,) + parts[0][0].shape[1:])
+        if name in ("a4", "th0", "Z"):
+            stride = -(-per_row // 32) * 32
+            got = tr.debug_read(name, rows * stride).reshape(rows, stride)[:, :per_row]
+        else:
+            got = tr.debug_read(name, rows * per_row).reshape((rows,) + parts[0][0].shape[1:])
         for arr, sl in parts:
             m = (got[sl] >= 0) != (arr >= 0)
             if m.any():

@@ -1,4 +1,4 @@
-"""One rank of tests/test_gpu_dp_two_ranks.py: a separate PROCESS that drives the C-ABI data-parallel path (ctx_dp_*) on its
+"""One rank of tests/test_gpu_dp_two_ranks.py (world 2, 4 or 8): a separate PROCESS that drives the C-ABI data-parallel path (ctx_dp_*) on its
 shard.  usage: python tests/_dp_rank_worker.py <rank> <world> <workdir>   (CTX_RCCL_LIB = the stand-in, set by the parent)"""
 import os
 import sys
@@ -74,7 +74,7 @@ def main():
             time.sleep(0.01)
         uid = open(idfile, "rb").read()
     tr.dp_init(uid, rank, world)
-    out = {"params0": tr.get_params_flat(), "adam_step0": np.int64(tr.get_adam_state()[2])}
+    out = {"params0": tr.get_params_flat(), "adam_step0": np.int64(tr.get_adam_state()[2]), "dp_world": np.array(tr.dp_world())}
     sl = slice(rank * SHARD, (rank + 1) * SHARD)
     dev = [torch.from_numpy(np.ascontiguousarray(x[sl])).cuda() for x in full_batch(world)]
     torch.cuda.synchronize()
@@ -169,6 +169,13 @@ def main():
     trs.dp_init(exchange_uid(work, "uid4.bin", rank), rank, world)
     trs.load_demos(demo_tensor())
     choices = sampled_choices(world)
+    # a global batch the ranks cannot split evenly is refused by EVERY rank before anything is enqueued (nobody is left in a collective)
+    from imitation_from_observation_amd import CtxError
+    try:
+        trs.dp_train_step_sampled(choices[0][0][:-1], choices[0][1][:-1], lr=1e-4)
+        out["ragged_refused"] = np.array(0)
+    except CtxError as e:
+        out["ragged_refused"] = np.array(int("multiple" in str(e)))
     ssc = []
     for cs, ct in choices:
         sc = trs.dp_train_step_sampled(cs, ct, lr=1e-4)

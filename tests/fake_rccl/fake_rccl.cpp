@@ -1,12 +1,12 @@
-// fake_rccl.cpp -- TEST INFRASTRUCTURE, not product: a stand-in for librccl that lets TWO PROCESSES ON ONE GPU run the
-// data-parallel path of libctxtrans (ctx_dp_init / ctx_dp_train_step / ctx_dp_scalars, include/ctxtrans.h) exactly as two
-// ranks on two GPUs would.  The build's gpurun boxes have one GPU; real RCCL refuses two ranks on one device, so without this
+// fake_rccl.cpp -- TEST INFRASTRUCTURE, not product: a stand-in for librccl that lets 2 ... 8 PROCESSES ON ONE GPU run the
+// data-parallel path of libctxtrans (ctx_dp_init / ctx_dp_train_step / ctx_dp_scalars, include/ctxtrans.h) exactly as N
+// ranks on N GPUs would.  The build's gpurun boxes have one GPU; real RCCL refuses two ranks on one device, so without this
 // the two-bucket / second-stream schedule of ctx_dp_train_step would first execute with N > 1 on the driver's 8-GPU node.
 //
 // Loaded through CTX_RCCL_LIB (ctxtrans.cpp: rccl_load), it exports the eight nccl* symbols the library binds.  Semantics kept:
 // collectives are ASYNCHRONOUS and STREAM-ORDERED (device->pinned copy, a host function on the stream that meets the other
 // ranks in a POSIX shared-memory segment, pinned->device copy); every rank sums the shards in rank order 0, 1, ..., so all
-// replicas receive bit-identical results (what a ring all-reduce also guarantees).  Every wait is bounded (30 s): a rank that
+// replicas receive bit-identical results (what a ring all-reduce also guarantees).  Every wait is bounded (30 s, FAKE_RCCL_TIMEOUT_S): a rank that
 // never arrives turns into ncclSystemError instead of a hung GPU box.
 //
 // Segment layout:  Header | rank 0 payload | rank 1 payload | ...   (payload capacity CAP bytes per rank, larger messages go in
@@ -30,7 +30,8 @@ namespace {
 
 constexpr size_t CAP = 8u << 20;           // bytes per rank per piece
 constexpr int MAXR = 8;
-constexpr double TIMEOUT_S = 30.0;
+// seconds a rank waits for the others at a barrier (FAKE_RCCL_TIMEOUT_S: eight processes starting on one box spread further than two)
+const double TIMEOUT_S = getenv("FAKE_RCCL_TIMEOUT_S") ? atof(getenv("FAKE_RCCL_TIMEOUT_S")) : 30.0;
 
 struct Header {
     std::atomic<int> arrived;              // barrier: arrivals of the current generation

@@ -435,3 +435,150 @@ def make_inception_v3_299():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "ref299":
     make_ref299()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The launch shapes bench.py's `secondary` numbers are quoted on: ContextAEReal at 36x64 with the
+# reference's own training batch 100 (ablations_code/ablations.py:503,536-544) and with 256, at 64x64 with 256; one GPU's share
+# of BASELINE configs[3] -- ContextAEInception2 on 2x2x2048 Mixed_7c maps (rllab/sampler/base.py:126), 64 triples.
+# Same scheme as make_b256: the float64 oracle runs the batch in chunks (`sim_batch` = the whole batch), the file holds seeds,
+# the four scalars, whole outputs of a few triples, per-triple digests of out / out2 / translated_z / input_z, and per gradient
+# tensor a digest, 16 random-sign projections and up to 4096 sampled entries; then ONE Adam step (lr 1e-4) in float64 and the
+# scalars of the pass after it, plus sampled entries of the parameter update where the gradient is well above the f32 noise floor.
+#   python tests/golden/make_golden.py big            (all four; ~10 minutes and ~12 GB here)
+# ------------------------------------------------------------------------------------------------------------------
+BIG_NPROJ, BIG_NSAMP = 16, 4096
+BIG_CASES = {
+    # tag: (kind, H, W, B, pseed, fseed, stddev, chunk)
+    "real_f100_36x64_b100": ("real", 36, 64, 100, 5100, 51, 0.1, 50),
+    "real_f100_36x64_b256": ("real", 36, 64, 256, 5256, 52, 0.1, 64),
+    "real_f100_64x64_b256": ("real", 64, 64, 256, 6256, 62, 0.1, 64),
+    "incep2_2x2x2048_f1024_b64": ("incep2", 2, 2, 64, 7064, 71, 0.02, 64),
+}
+
+
+def big_case(tag):
+    """(oracle module, cfg, params {name: float32-representable float64}, [src, ctx, tgt] float32 inputs) -- also what the GPU test
+    rebuilds.  ContextAEReal: smooth blob frames for slot 0 / 2 and iid frames for the context slot (both SURVEY 8d distributions in one
+    batch); ContextAEInception2: post-ReLU maps."""
+    kind, H, W, B, pseed, fseed, stddev, _ = BIG_CASES[tag]
+    if kind == "real":
+        from oracle import ctx_oracle_real as mod
+        cfg = mod.RealConfig(H=H, W=W)
+    else:
+        from oracle import ctx_oracle_incep as mod
+        cfg = mod.Incep2Config(H=H, W=W)
+    p = mod.init_params(cfg, pseed, np.float32, stddev=stddev)
+    brng = np.random.default_rng(pseed + 1)
+    for n in p:
+        if n.endswith("bias") or n.endswith("biases"):
+            p[n] = (brng.standard_normal(p[n].shape) * stddev).astype(np.float32)
+    if kind == "real":
+        u8 = [blob_frames(fseed, B, H, W), synth_frames(fseed + 1, B, H, W), blob_frames(fseed + 2, B, H, W)]
+        x = [o.preprocess_u8(f) for f in u8]
+    else:
+        frng = np.random.default_rng(fseed)
+        x = [np.maximum(frng.standard_normal((B, H, W, cfg.C)), 0.0).astype(np.float32) for _ in range(3)]
+    return mod, cfg, p, x
+
+
+def big_probes(name_sizes, tag):
+    base = BIG_CASES[tag][4]
+    out = {}
+    for i, (n, size) in enumerate(name_sizes):
+        idx = np.sort(np.random.default_rng(base * 1000 + i).choice(size, min(BIG_NSAMP, size), replace=False))
+        out[n] = (base * 2000 + i, idx)
+    return out
+
+
+def big_project(a, seed):
+    a = np.asarray(a, np.float64).reshape(-1)
+    rng = np.random.default_rng(seed)
+    return np.array([float(a @ (rng.integers(0, 2, a.size, dtype=np.int8) * 2.0 - 1.0)) for _ in range(BIG_NPROJ)])
+
+
+def _big_pass(mod, cfg, p, x, B, chunk, want_grads=True):
+    names = [n for n, _ in mod.param_specs(cfg)]
+    g = {n: np.zeros_like(p[n]) for n in names} if want_grads else None
+    scal = np.zeros(3)
+    outs = {k: [] for k in ("out", "out2", "translated_z", "input_z")}
+    neg, near, size = {}, {}, {}
+    for i0 in range(0, B, chunk):
+        sl = slice(i0, min(B, i0 + chunk))
+        res, c = mod.forward(p, *(a[sl].astype(np.float64) for a in x), cfg)
+        scal += [res["recon1"], res["recon2"], float(np.sum((c["trans_z"] - c["e_tgt"][5]) ** 2))]
+        for k in outs:
+            outs[k].append(res[k])
+        if want_grads:
+            gi = mod.backward(p, c, cfg, sim_batch=B)
+            for n in names:
+                g[n] += gi[n]
+            # lrelu'-relevant activations under the device's buffer names (tests/_align.py: align_gen_cache)
+            bufs = {f"a{k}": (c["e_tgt"][k], c["e_src"][k], c["e_ctx"][k]) for k in range(5)}
+            bufs["z"] = (c["e_tgt"][5], c["e_src"][5])
+            bufs["th0"] = (c["trans_h0"],)
+            bufs["dz"] = (c["d1"][0], c["d2"][0])
+            for k in (1, 2, 3):
+                bufs[f"e{k}"] = (c["d1"][k], c["d2"][k])
+            for k, parts in bufs.items():
+                for a in parts:
+                    neg[k] = neg.get(k, 0) + int((a < 0).sum())
+                    near[k] = near.get(k, 0) + int((np.abs(a) <= 1e-6 * np.abs(a).max()).sum())
+                    size[k] = size.get(k, 0) + a.size
+    F = cfg.featsize
+    sim = scal[2] / (B * F) * 1e3
+    scalars = np.array([scal[0] + scal[1] + sim, sim, scal[0], scal[1]])
+    return scalars, {k: np.concatenate(v) for k, v in outs.items()}, g, (neg, near, size)
+
+
+def make_big(tag):
+    import time
+    t0 = time.time()
+    kind, H, W, B, pseed, fseed, stddev, chunk = BIG_CASES[tag]
+    mod, cfg, p32, x = big_case(tag)
+    p = {k: v.astype(np.float64) for k, v in p32.items()}
+    names = [n for n, _ in mod.param_specs(cfg)]
+    keep = sorted({0, B // 3, B - 1})
+    fx = dict(kind=kind, cfg=np.array([H, W, cfg.C, cfg.featsize]), B=B, pseed=pseed, fseed=fseed, stddev=stddev, lr=1e-4, keep=np.array(keep))
+    fx["param_digest"], _ = digest(mod.flatten(p, cfg))
+    fx["input_digest"] = np.stack([digest(a)[0] for a in x])
+    scalars, outs, g, (neg, near, size) = _big_pass(mod, cfg, p, x, B, chunk)
+    print(f"{tag}: pass 1 {time.time() - t0:.0f}s loss {scalars[0]:.8g}", flush=True)
+    fx["scalars"] = scalars
+    for k, full in outs.items():
+        fx[k + "_keep"] = full[keep].astype(np.float32)
+        flat = full.reshape(B, -1)
+        fx[k + "_rows"] = np.stack([flat.sum(1), np.abs(flat).sum(1), np.sqrt((flat * flat).sum(1))], 1)
+    probes = big_probes([(n, g[n].size) for n in names], tag)
+    fx["grad_digest"] = np.stack([digest(g[n])[0] for n in names])
+    fx["grad_proj"] = np.stack([big_project(g[n], probes[n][0]) for n in names])
+    fx["grad_samples"] = np.stack([np.pad(g[n].reshape(-1)[probes[n][1]], (0, BIG_NSAMP - len(probes[n][1]))) for n in names])
+    fx["act_names"] = np.array(sorted(neg))
+    fx["act_negative"] = np.array([neg[k] for k in sorted(neg)], np.int64)
+    fx["act_near_zero"] = np.array([near[k] for k in sorted(neg)], np.int64)
+    fx["act_size"] = np.array([size[k] for k in sorted(neg)], np.int64)
+    # one TF-Adam step (train_script.py:128,163) in float64, then the scalars of the next pass
+    p0 = {n: p[n].copy() for n in names}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(v_) for k, v_ in p.items()}
+    o.adam_step(p, g, m, v, 1, 1e-4)
+    # the update of an entry is -lr * sign(g) (first step): it is well-defined where |g| is above the f32 noise floor of its tensor
+    upd = []
+    for n in names:
+        idx = probes[n][1]
+        gs = g[n].reshape(-1)[idx]
+        d = (p[n] - p0[n]).reshape(-1)[idx]
+        d = np.where(np.abs(gs) > 1e-3 * np.abs(g[n]).max(), d, np.nan)
+        upd.append(np.pad(d, (0, BIG_NSAMP - len(idx)), constant_values=np.nan))
+    fx["update_samples"] = np.stack(upd)
+    del g, p0, m, v
+    scalars2, _, _, _ = _big_pass(mod, cfg, p, x, B, chunk, want_grads=False)
+    fx["train_scalars"] = np.stack([scalars, scalars2])
+    path = os.path.join(HERE, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(tag, os.path.getsize(path), "bytes; loss", scalars[0], "->", scalars2[0], f"{time.time() - t0:.0f}s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "big":
+    for _tag in (sys.argv[2:] or list(BIG_CASES)):
+        make_big(_tag)

@@ -16,12 +16,16 @@ python - <<PY
 import csv, glob, collections, re
 O="$O"; PAT="$PAT"
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+clk=collections.defaultdict(list)
 for f in glob.glob(O+"/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
         if not re.search(PAT, k): continue
         k=re.sub(r"^void |ctx::|\(anonymous namespace\)::", "", k).split("(")[0][:70]+" grid="+r.get("Grid_Size","?")
         agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[(k,r["Counter_Name"])]+=1
+        if r["Counter_Name"]=="GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):      # effective shader clock of the launch (MI355X_MICROARCH.md, DVFS give-back)
+            dt=float(r["End_Timestamp"])-float(r["Start_Timestamp"])
+            if dt>0: clk[k].append((float(r["Counter_Value"])/dt, dt*1e-3))
 with open(O+"/summary.txt","w") as out:
     for k,v in sorted(agg.items()):
         out.write(k+"\n")
@@ -29,6 +33,8 @@ with open(O+"/summary.txt","w") as out:
             out.write(f"    {c:28s} {x/cnt[(k,c)]:16.0f}  per launch (n={cnt[(k,c)]})\n")
         if v.get("SQ_BUSY_CYCLES") and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             out.write(f"    mfma busy / (32 * busy)      {v['SQ_VALU_MFMA_BUSY_CYCLES']/cnt[(k,'SQ_VALU_MFMA_BUSY_CYCLES')]/(32*v['SQ_BUSY_CYCLES']/cnt[(k,'SQ_BUSY_CYCLES')]):.3f}\n")
+        if clk[k]:
+            out.write(f"    effective clock GRBM_GUI_ACTIVE / duration: {sum(c for c,_ in clk[k])/len(clk[k]):.3f} GHz over {sum(d for _,d in clk[k])/len(clk[k]):.1f} us launches (profiled pass: serialised, counters on)\n")
         a=lambda c: v[c]/cnt[(k,c)] if cnt[(k,c)] else 0.0
         if a("SQ_WAVE_CYCLES"):
             out.write(f"    of the wave cycles: waiting on any instruction {a('SQ_WAIT_INST_ANY')/a('SQ_WAVE_CYCLES'):.2f}, on LDS {a('SQ_WAIT_INST_LDS')/a('SQ_WAVE_CYCLES'):.2f}, issuing {a('SQ_ACTIVE_INST_ANY')/a('SQ_WAVE_CYCLES'):.2f}\n")
