@@ -177,7 +177,7 @@ int run(ctx_cnn* h, int n, std::vector<hipEvent_t>* ev = nullptr) {
                 b.ntap = op.kh * op.kw; b.cs = in.c;
                 conv3_fwd(st, a, b, ep, R, op.cout, ws);
             } else if (h->precision == CTX_PREC_F32 && opt(OPT_CNN_DCONV) && op.kh == op.kw && cin >= 8 && (cin & (cin - 1)) == 0 && dconv_ok(cin, op.cout) &&
-                       (opt(OPT_CNN_DCONV) >= 2 || (cin <= 32 && op.cout <= 32))) {
+                       cin <= 32 && op.cout <= 32) {
                 // Conv2d_2a_3x3 (32 -> 32): a 32-column GEMM wastes the implicit GEMM's tiles (57 TF/s); the direct convolution over an LDS
                 // halo tile with the filter resident (dconv.h) runs it at 81 (0.223 -> 0.157 ms at 192 images of 125x125).  Wider layers lose:
                 // 32 -> 64 0.271 -> 0.399 ms, 64 -> 80 1x1 0.076 -> 0.125, 64 -> 96 0.048 -> 0.092 (option value 2 runs them all)

@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>   // types and enums only: the library itself is dlopen()ed by ctx_dp_init (no link-time dependency)
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -621,7 +622,6 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
         P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
         dconv_conv(h->stream, P, 2, 1);
     } else if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
-    else if (h->cfg.precision == CTX_PREC_F32 && wconv_ok(hs, ws, ca, cb, nimg, ep)) wconv_fwd(h->stream, x, ca, nimg, hs, ws, w, cb, ep);
     else if (use_q(nimg)) conv_fwd_q(h->stream, KmConvGatherQ{x, ca, make_posgeo(hs, ws, hb, wb, 2, 1, 5, ca / KC), nimg, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ep, cb, ws_of(h));
     else conv_fwd(h->stream, KmConvGather{x, ca, hb, wb, hs, ws, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ep, R, cb, ws_of(h));
 }
@@ -841,8 +841,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
                   conv_wgrad2_p(h->stream, NmWgradBigP{dy, ca, ca, wb, pg, g_zeros}, NmWgradSmall2P{dec_in, c1, c1, h->c[4 - k], c2, B, cb, pg, g_zeros}, eg, ca, cb, ws_of(h));
               } else conv_wgrad2(h->stream, NmWgradBig{dy, ca, ca, hb, wb, make_pixdiv(hs, wsm), R, g_zeros}, small, eg, ca, cb, ws_of(h)); }
             { ProfScope ps(h, nm_ + " dx", K_CONV, fl, uf);
-              if (h->cfg.precision == CTX_PREC_F32 && wconv_ok(hs, wsm, ca, cb, 2 * B, ed)) wconv_fwd(h->stream, dy, ca, 2 * B, hs, wsm, w, cb, ed);
-              else if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
+              if (use_q(2 * B)) conv_fwd_q(h->stream, KmConvGatherQ{dy, ca, make_posgeo(hs, wsm, hb, wb, 2, 1, 5, ca / KC), 2 * B, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ed, cb, ws_of(h));
               else conv_fwd(h->stream, KmConvGather{dy, ca, hb, wb, hs, wsm, ca / KC, R, g_zeros}, nm(w, cb, cb, 25 * ca), ed, R, cb, ws_of(h)); }
         }
         dy = d_dec;
@@ -1212,7 +1211,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
         h->use_graphs = h->opt.v[OPT_GRAPHS] != 0;
         // Side-lane stream priority: NORMAL.  (Lowest was -0.03 ms on the ContextSkipNew step and -0.7 ms on the split-bf16 config-4
         // step, but the f32 config-4 step -- front end chained on the same stream -- went from 7.8 to 17.4 ms with it; highest +0.08 ms.)
-        const int lane_prio = h->opt.v[OPT_LANE_PRIO];
+        const int lane_prio = 0;
         for (int l = 0; l < ctx_handle::NLANE && rc == CTX_OK; ++l)
             if (hipStreamCreateWithPriority(&h->aux[l], hipStreamNonBlocking, lane_prio) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork[l], hipEventDisableTiming) != hipSuccess ||
@@ -1704,9 +1703,16 @@ int ctx_set_option(ctx_handle* h, const char* name, int value) {
     if (!h) return CTX_E_INVALID;
     const int i = opt_find(name);
     if (i < 0) return fail(h, CTX_E_INVALID, "unknown option '%s'", name ? name : "(null)");
-    // options that decided the handle's buffers or kernels' parameter layouts at ctx_create cannot change afterwards
-    if ((i == OPT_DIRECT3 || i == OPT_DCONV) && value != h->opt.v[i])
-        return fail(h, CTX_E_STATE, "option '%s' is fixed at ctx_create (it decides buffers and layouts): set CTX_%s in the environment before creating the handle", opt_name(i), "<NAME>");
+    // options that decided the handle's buffers, kernel parameter layouts or streams at ctx_create (and the ctx_cnn handles' switches,
+    // which a translator handle never reads) cannot change afterwards: refusing beats a silent no-op that reads back as set
+    const bool create_only = i == OPT_DIRECT3 || i == OPT_DCONV || i == OPT_ADAM_PRIO || i == OPT_CNN_LANES || i == OPT_CNN_DCONV || i == OPT_CNN_STEM4;
+    if (create_only && value != h->opt.v[i]) {
+        char up[32] = {};
+        const char* nm = opt_name(i);
+        for (size_t c = 0; nm[c] && c + 1 < sizeof up; ++c) up[c] = (char)toupper((unsigned char)nm[c]);
+        return fail(h, CTX_E_STATE, "option '%s' is fixed at ctx_create (it decides buffers, layouts or streams): set CTX_%s in the environment before creating the handle", nm, up);
+    }
+    if (i == OPT_OVERLAP && value < 0) value = !(h->gen && h->H * h->W < 64);      // -1 = by size, resolved as ctx_create does; reads back 0 / 1
     h->opt.v[i] = value;
     if (i == OPT_OVERLAP) h->overlap = value != 0;
     if (i == OPT_GRAPHS) {

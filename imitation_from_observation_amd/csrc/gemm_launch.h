@@ -140,7 +140,7 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
             // (the heavy / light pairing distance only matters for a launch of about one round of resident blocks; a longer one gets
             // the plain alternation, which keeps every window of the slot sequence near the mean)
             const bool one_round = tiles * nsplit <= 3 * (int64_t)dev_info().cus;
-            ep.perm = balanced_order(prob_weight, nprob, nbins, one_round ? (int)(tiles / nprob) : 32);
+            ep.perm = balanced_order(prob_weight, nprob, nbins, one_round ? (int)(tiles / nprob) : 32, s);
         }
     }
     // narrow operands (ContextAEReal's 32-channel layers): tiles that do not multiply zeros.  f32 only.

@@ -48,7 +48,7 @@ namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[OPT_COUNT] = {
     {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 15}, {"direct3", 15}, {"dconv", 1},
-    {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"wconv", 0}, {"lane_prio", 0}, {"adam_prio", 2},
+    {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"adam_prio", 2},
 };
 }  // namespace
 thread_local const Options* g_opt = nullptr;
@@ -82,7 +82,7 @@ int opt(Opt o) {
 }
 int balance_bits() { return opt(OPT_BALANCE); }
 
-const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem) {
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem, hipStream_t stream) {
     if (nprob <= 1 || nprob > 65535 || nbins < 1) return nullptr;
     static std::mutex mu;
     static std::map<std::pair<int, std::vector<int>>, uint16_t*> cache;
@@ -94,6 +94,8 @@ const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tile
     std::lock_guard<std::mutex> g(mu);
     auto it = cache.find({dev, key});
     if (it != cache.end()) return it->second;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return nullptr;   // no synchronous work inside a capture
     // longest-first greedy into nbins runs of at most ceil(nprob / nbins) problems
     std::vector<int> idx(nprob);
     for (int i = 0; i < nprob; ++i) idx[i] = i;

@@ -28,7 +28,10 @@ void ensure_dyn_lds(const void* kernel, size_t bytes);
 // of (nearly) equal length by longest-first greedy, heavy and light problems placed inside a run so that the two blocks that share
 // a CU (blocks l and l + 32 of an XCD's run) are a heavy and a light one, and returns the order as a DEVICE array of nprob uint16 (cached per weight vector and device;
 // created on first use -- a synchronous 2 * nprob-byte copy).  Same problems, same arithmetic per problem: results do not change.
-const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem);
+// A first use that lands inside a stream capture (a caller capturing its own stream around a handle made by ctx_create_ex) must not
+// allocate or copy synchronously -- that would invalidate the capture: it returns nullptr (the kernel's plain order) and the next
+// un-captured launch of that shape creates the entry.
+const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem, hipStream_t stream);
 // CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (the 4x4
 // layers: d_h1's input gradient 0.675 -> 0.59 ms, h3_conv forward 0.352 -> 0.316); 2 = on larger grids too (with the pair-aware order
 // inside a run: -0.03 ms of step; before it the scattered positions of an 8x8 grid cost more L2 misses than the 7.5 % imbalance);
@@ -104,9 +107,6 @@ void c3conv(hipStream_t s, const float* x, int nimg, int hin, int win, int strid
 // conv2d_transpose 5x5 stride 2 for wide channel counts on the 8x8 / 16x16 grids: image-major, input halo tile resident in LDS
 // (wconvt.hip).  in = [s1 | s2] (s2 = ctx skip with image index img % nmod2; c2 = 0: none), filter w[5][5][ca][c1 + c2].
 bool wconvt_ok(int hs, int ws, int c1, int c2, int ca, int nimg);
-// conv2d 5x5 stride 2 SAME onto a ho x wo grid with the input halo tile resident in LDS (wconv.hip): x [nimg, 2 ho, 2 wo, ci], filter w[5][5][ci][co]
-bool wconv_ok(int ho, int wo, int ci, int co, int nimg, const Epi& ep);
-void wconv_fwd(hipStream_t s, const float* x, int ci, int nimg, int ho, int wo, const float* w, int co, const Epi& ep);
 void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2, int nmod2, int nimg, int hs, int ws, const float* w, int ca,
                 const Epi& ep, SplitWs ws_);
 

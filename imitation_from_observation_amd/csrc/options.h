@@ -21,12 +21,9 @@ enum Opt {
     OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms, round 4)
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on
     OPT_CNN_DCONV,     // Inception front end, f32: 1 = layers of <= 32 input and output channels (Conv2d_2a_3x3) on the direct kernels of dconv.h;
-                       // 2 = every layer they are instantiated for (measured slower); 0 = implicit GEMM
+                       // 0 = implicit GEMM
     OPT_CNN_STEM4,     // 1: the front end's 3-channel first conv on the 4-channel gather
     OPT_TRACE_LAUNCH,  // 1: one stderr line per distinct implicit-GEMM launch shape (diagnostics)
-    OPT_WCONV,         // 1: stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills
-                       // the chip, 2: whatever its size; 0 (default): position-major implicit GEMM.  Measured: 2-4 % faster alone, step +0.05 ms
-    OPT_LANE_PRIO,     // HIP priority of the side-lane streams, read at create: 0 normal, -1 high, 1 low (a priority class has its own hardware queues)
     OPT_ADAM_PRIO,     // HIP priority of the early-Adam stream, read at create: 1 low (its own hardware queue), 0 normal, -1 high; 2 (default) = 1 for
                        // exact-f32 handles, 0 for split-bf16 ones; reads back resolved
     OPT_COUNT

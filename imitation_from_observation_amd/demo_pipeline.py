@@ -94,14 +94,20 @@ def inverse_transform(images):
     return (images + 1.) / 2.
 
 
-def build_vdata(videos, idims, nvideos, nlen, nskip, rescale=True, inception=False, log=None, max_fail=10):
+def build_vdata(videos, idims, nvideos, nlen, nskip, rescale=True, inception=False, log=None, max_fail=10, shuffle=True, return_count=False):
     """train_script.py:59-96 from `videos`, an iterable of decoded demo videos: arrays [nframes, H, W, 3] uint8 or zero-argument
     callables returning one (so that decoding errors are counted like the reference's `except:`).  Only videos of exactly 51 frames
     are used (:72); frames 1, 1 + nskip, ... < 51 are transformed (:74-75); a video whose first kept frames contain an all -1 frame
     -- black -- is dropped unless `inception` (:76-79); it must yield exactly nlen frames (:81).  Stops after `nvideos` videos were
     LOOKED AT (the reference counts every readable 51-frame video, kept or not, :87, :94) or after more than `max_fail` read errors.
-    Returns vdata [nlen, n_kept, h, w, 3] (float64 in [-1, 1] when rescale, else uint8)."""
+    shuffle (default, as the reference): `np.random.shuffle(videos)` on the list first (:66) -- it decides which videos land in the
+    train / validation split and moves the global np.random stream the trainer draws its batches from afterwards, exactly as there.
+    Returns vdata [nlen, n_kept, h, w, 3] (float64 in [-1, 1] when rescale, else uint8); with return_count also `itr`, the number of
+    videos looked at -- the reference names its saved tensor after it (`vdata_strike` + str(itr), :95)."""
     log = log or (lambda s: None)
+    if shuffle:
+        videos = list(videos)
+        np.random.shuffle(videos)                              # train_script.py:66
     idata = [[] for _ in range(nlen)]
     nfail = 0
     itr = 0
@@ -135,4 +141,4 @@ def build_vdata(videos, idims, nvideos, nlen, nskip, rescale=True, inception=Fal
             break
     vdata = np.array(idata)
     log(str(vdata.shape))
-    return vdata
+    return (vdata, itr) if return_count else vdata

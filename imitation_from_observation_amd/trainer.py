@@ -16,7 +16,8 @@ What differs, and why:
   * mp4 DECODING (:69, imageio + ffmpeg) is not available here: the demo tensor comes in as an array or a `.npy` path (the file
     the reference itself saves), or as `videos=` -- decoded videos [51, H, W, 3] uint8 -- which then go through the reference's own
     loop (:59-96: frame selection by nskip, `transform` = scipy.misc.imresize bilinear + /127.5 - 1, black-frame drop; restated in
-    demo_pipeline.py, the resize bit-exact against Pillow) and are saved as `<basedir>vdata_strike<n>.npy` like :95;
+    demo_pipeline.py, the resize bit-exact against Pillow; the list is shuffled with np.random first, :66) and are saved as
+    `<basedir>vdata_strike<itr>.npy` like :95 (itr = the videos looked at);
   * the sess.run calls are `Translator.train_step_sampled` / `eval_sampled` on the demo tensor resident in HBM (uint8;
     `gather_triples_kernel` builds the batch with the trainer's x / 127.5 - 1 scaling) when the float demo tensor lies
     exactly on that uint8 lattice -- bit-identical to feeding the host-gathered float batch -- and
@@ -24,7 +25,8 @@ What differs, and why:
   * `nn_err` (:148) reads `featreshape`, which only exists in the Inception branch (NameError for the other
     models).  Its intended meaning -- for every output j the index of the nearest tgt frame, compared with j % nlen -- is
     computed on the host from `out` and the tgt slot for every model;
-  * clips are stored as uint8 arrays `__<k>trans.npy` / `__<k>recon.npy` (imageio absent), same frames the gifs would hold;
+  * clips are written as `__<k>trans.gif` / `__<k>recon.gif` like :23-26, :193-194 -- by Pillow (imageio is absent), the frames
+    `(clip(inverse_transform(f), 0, 1) * 255).astype(uint8)`; a box without Pillow gets the same frames as `.npy`;
   * the tabular log is a CSV `<basedir>progress.csv` (rllab's logger is outside the hot path).  As in the reference, on a
     save iteration its R1 / R2 columns hold the LAST CLIP's recon1 / recon2 (the clip loop re-uses the names, :192-193),
     while Loss / Sim / NNErr stay the validation batch's.
@@ -47,6 +49,19 @@ import os
 import numpy as np
 
 LEARNING_RATE = 1e-4          # fed at every step, train_script.py:163,167
+
+
+def save_clip(stem, frames_u8):
+    """savegif (train_script.py:22-26): one GIF of the uint8 frames [n, H, W, 3], 100 ms each, written by Pillow (which folds a frame equal
+    to its predecessor into that one's display time: the animation is the same); `.npy` where Pillow is missing."""
+    try:
+        from PIL import Image
+    except ImportError:
+        np.save(stem, frames_u8)
+        return stem + ".npy"
+    ims = [Image.fromarray(np.ascontiguousarray(f)) for f in frames_u8]
+    ims[0].save(stem + ".gif", save_all=True, append_images=ims[1:], loop=0, duration=100)
+    return stem + ".gif"
 
 
 def nn_err(tgt, out, nlen, j0=0):
@@ -146,10 +161,10 @@ class ModelTrainer:
         os.makedirs(basedir, exist_ok=True)
         if self.vdata is None and self.videos is not None:
             from .demo_pipeline import build_vdata
-            vdata = build_vdata(self.videos, self.idims, self.nvideos, self.nlen, self.nskip, self.rescale, self.inception,
-                                log=self.log if self.rank == 0 else None)
+            vdata, looked_at = build_vdata(self.videos, self.idims, self.nvideos, self.nlen, self.nskip, self.rescale, self.inception,
+                                           log=self.log if self.rank == 0 else None, return_count=True)
             if self.rank == 0:
-                np.save(basedir + "vdata_strike" + str(vdata.shape[1]), vdata)                 # train_script.py:95
+                np.save(basedir + "vdata_strike" + str(looked_at), vdata)                      # train_script.py:95 (named after `itr`, the videos looked at)
         else:
             vdata = np.load(self.vdata) if isinstance(self.vdata, (str, os.PathLike)) else np.asarray(self.vdata)
         if vdata.ndim != 5 or vdata.shape[2:4] != self.idims or vdata.shape[0] < self.nlen:
@@ -260,10 +275,11 @@ class ModelTrainer:
                                     lo, hi = max(j0, 0), min(j0 + Bl, nlen)
                                     if hi > lo:
                                         head[lo:hi] = frames[lo - j0:hi - j0]
-                                    frames = allsum(head.ravel()).reshape(head.shape)
+                                    # (the group sums in float64; the quantisation below is the single-GPU path's and the reference's float32 arithmetic)
+                                    frames = allsum(head.ravel()).reshape(head.shape).astype(np.float32)
                                 u = (np.clip((frames[:nlen] + 1.0) / 2.0, 0, 1) * 255).astype(np.uint8)     # savegif's frames (:23-26)
                                 if rank == 0:
-                                    np.save("%s%d/__%d%s" % (basedir, itr, kk, tag), u)
+                                    save_clip("%s%d/__%d%s" % (basedir, itr, kk, tag), u)
                 if itr >= self.save_every and rank == 0:
                     rows.append(dict(Iteration=itr, Loss=loss, Sim=sim, R1=r1, R2=r2, NNErr=err))
                     with open(basedir + "progress.csv", "w", newline="") as f:

@@ -51,7 +51,7 @@ class _ResultPool:
     Only arrays of >= `min_bytes` are pooled (small ones come from malloc's free lists and are warm anyway)."""
 
     def __init__(self, min_bytes=1 << 20, keep=4):
-        self.min_bytes, self.keep, self._free = min_bytes, keep, {}
+        self.min_bytes, self.keep, self._free, self._idle = min_bytes, keep, {}, None
 
     def get(self, shape, dtype=np.float32):
         import sys
@@ -60,9 +60,15 @@ class _ResultPool:
         if nbytes < self.min_bytes:
             return np.empty(shape, dtype)
         lst = self._free.setdefault((shape, np.dtype(dtype).str), [])
+        # What an array nobody else holds counts here -- the list, the loop variable, getrefcount's argument on CPython 3.10; fewer on
+        # interpreters that borrow references -- is MEASURED on a probe in the same loop shape, not assumed: anything above it is a
+        # caller (or a view of one)
+        if self._idle is None:
+            probe = [np.empty(1, np.uint8)]
+            for a in probe:
+                self._idle = sys.getrefcount(a)
         for a in lst:
-            # references: the list, the loop variable, getrefcount's argument -- anything more is a caller (or a view of one)
-            if sys.getrefcount(a) == 3:
+            if sys.getrefcount(a) == self._idle:
                 return a
         a = np.empty(shape, dtype)
         if len(lst) < self.keep:

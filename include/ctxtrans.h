@@ -129,15 +129,12 @@ const char* ctx_last_error(const ctx_handle* h);
  *   dconv        1   ContextAEReal in f32 on the narrow-channel direct kernels                                          [fixed at create]
  *   rchain       1   ContextAEReal's FC middle in three launches
  *   early_adam   1   Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms)
- *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create)
- *   cnn_dconv    1   Inception front end (f32): layers of <= 32 input and output channels on the direct kernels (dconv.h); 2 = every eligible layer
- *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create)
+ *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create) [fixed at create]
+ *   cnn_dconv    1   Inception front end (f32): layers of <= 32 input and output channels on the direct kernels (dconv.h); 0 = implicit GEMM  [fixed at create]
+ *   cnn_stem4    1   Inception front end: the 3-channel first conv on the 4-channel gather    (ctx_cnn handles: environment at create) [fixed at create]
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
- *   wconv        0   1 = stride-2 convolutions onto 16x16 / 8x8 grids with the input tile resident in LDS (wconv.hip) where the launch fills the
- *                    chip, 2 = at any size; 0 = position-major implicit GEMM (2-4 % slower alone, the whole step 0.05 ms faster)
- *   lane_prio    0   HIP priority of the side-lane streams (0 normal, -1 high, 1 low); read at create only
  *   adam_prio    2   HIP priority of the early-Adam stream (1 low: its own hardware queue; 0 normal; -1 high; 2 = low for exact-f32 handles,
- *                    normal for split-bf16 ones, reads back resolved); read at create only
+ *                    normal for split-bf16 ones, reads back resolved)  [fixed at create]
  * Results never depend on a switch beyond f32 summation order.  Not options: CTX_RCCL_LIB (path of the librccl to dlopen, read by the
  * first ctx_dp_* call of the process). */
 int ctx_option_count(void);

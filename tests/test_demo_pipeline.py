@@ -56,16 +56,37 @@ def test_transform_and_video_loop():
         raise IOError("cannot decode")
 
     logs = []
-    vdata = build_vdata([good[0], short, black, broken, good[1], good[2], good[3]], (32, 32), nvideos=4, nlen=25, nskip=2, log=logs.append)
+    vdata = build_vdata([good[0], short, black, broken, good[1], good[2], good[3]], (32, 32), nvideos=4, nlen=25, nskip=2, log=logs.append, shuffle=False)
     # looked at: good0 (kept, 1), short (counted, not kept, 2), black (`continue`: NOT counted), broken (error), good1 (3), good2 (4) -> stop before good3
     assert vdata.shape == (25, 3, 32, 32, 3) and vdata.dtype == np.float64
     np.testing.assert_array_equal(vdata[0, 0], transform(good[0][1], 32, 32, True))
     np.testing.assert_array_equal(vdata[24, 2], transform(good[2][49], 32, 32, True))
     assert any(s.startswith("rip") for s in logs) and any("Unexpected error" in s for s in logs) and logs[-1] == str(vdata.shape)
-    u8 = build_vdata(good, (40, 40), nvideos=4, nlen=25, nskip=2, rescale=False)
+    u8 = build_vdata(good, (40, 40), nvideos=4, nlen=25, nskip=2, rescale=False, shuffle=False)
     assert u8.dtype == np.uint8 and u8.shape == (25, 4, 40, 40, 3)
     np.testing.assert_array_equal(u8[3, 1], good[1][7])        # same size: frames pass through untouched
     # and the tensor feeds the trainer's device sampler: it lies on the uint8 lattice
     from imitation_from_observation_amd.trainer import on_u8_lattice
     k, ok = on_u8_lattice(build_vdata(good, (32, 32), nvideos=4, nlen=25, nskip=2))
     assert ok and k.dtype == np.uint8
+
+
+def test_build_vdata_shuffles_like_the_reference_and_reports_the_videos_looked_at():
+    """train_script.py:66 `np.random.shuffle(videos)` decides the video order (hence the train / validation split) and moves the
+    global np.random stream; :95 names the saved tensor after `itr`, the videos LOOKED AT -- not the videos kept."""
+    rng = np.random.default_rng(5)
+    good = [rng.integers(1, 256, (51, 20, 20, 3), dtype=np.uint8) for _ in range(6)]
+    short = rng.integers(1, 256, (30, 20, 20, 3), dtype=np.uint8)            # counted (itr += 1), not kept
+    vids = good[:3] + [short] + good[3:]
+    np.random.seed(11)
+    vdata, looked_at = build_vdata(vids, (20, 20), nvideos=7, nlen=25, nskip=2, return_count=True)
+    after = np.random.get_state()[1][:4].copy()
+    np.random.seed(11)
+    order = list(range(7))
+    np.random.shuffle(order)                                                  # the same permutation the list got
+    np.testing.assert_array_equal(np.random.get_state()[1][:4], after)       # the stream is left where the reference leaves it
+    kept = [i for i in order if i != 3]
+    assert looked_at == 7 and vdata.shape[1] == 6
+    for col, i in enumerate(kept):
+        np.testing.assert_array_equal(vdata[0, col], transform(vids[i][1], 20, 20, True))
+    assert order != sorted(order)

@@ -16,6 +16,17 @@ CFG = o.SkipNewConfig(H=H, W=W, df_dim=4, gf_dim=4, featsize=8)
 B, NLEN, NVID, NTRAIN, NITR, SAVE = 6, 3, 8, 5, 45, 20
 
 
+def read_clip(path):
+    """frames [n, H, W, 3] uint8 of a clip written by trainer.save_clip (a GIF: palette colours, so compare clips with clips).  Pillow's
+    writer folds a frame that equals its predecessor into the predecessor's display time: a frame shown for k x 100 ms counts k times."""
+    from PIL import Image, ImageSequence
+    with Image.open(path) as im:
+        out = []
+        for f in ImageSequence.Iterator(im):
+            out += [np.asarray(f.convert("RGB"))] * max(1, int(round(f.info.get("duration", 100) / 100)))
+        return np.stack(out)
+
+
 class OracleModel:
     """The four sess.run sites on the oracle: the surface ModelTrainer drives."""
 
@@ -129,8 +140,8 @@ def test_trainer_equals_the_reference_loop(tmp_path):
     np.testing.assert_array_equal(np.load(base + "vdata_train.npy"), vdata[:, :NTRAIN][:, :200])
     np.testing.assert_array_equal(np.load(base + "40/validloss.npy"), validloss)
     assert sorted(f for f in os.listdir(base + "20") if f.startswith("__")) == sorted(
-        [f"__{k}{t}.npy" for k in range(10) for t in ("trans", "recon")])
-    clip = np.load(base + "20/__0trans.npy")
+        [f"__{k}{t}.gif" for k in range(10) for t in ("trans", "recon")])      # savegif's names (train_script.py:193-194)
+    clip = read_clip(base + "20/__0trans.gif")
     assert clip.dtype == np.uint8 and clip.shape == (NLEN, H, W, 3)
     with open(base + "progress.csv") as f:
         table = list(csv.reader(f))
@@ -219,8 +230,11 @@ def test_trainer_builds_the_demo_tensor_from_decoded_videos(tmp_path):
     t = ModelTrainer((H, W), NVID, NTRAIN, B, "ContextSkipNew", 9, 8, NLEN, nskip, vdata=None, videos=videos, basedir=base,
                      translator=OracleModel(3), log=lines.append)
     t.train()
-    saved = np.load(base + "vdata_strike%d.npy" % NVID)
+    saved = np.load(base + "vdata_strike%d.npy" % NVID)            # named after the videos looked at (train_script.py:95)
     assert saved.shape == (NLEN, NVID, H, W, 3)
-    np.testing.assert_array_equal(saved[1, 2], transform(videos[2][18], H, W, True))
+    np.random.seed(3)
+    order = list(range(NVID))
+    np.random.shuffle(order)                                      # train_script.py:66: the list is shuffled before the loop
+    np.testing.assert_array_equal(saved[1, 2], transform(videos[order[2]][18], H, W, True))
     assert on_u8_lattice(saved)[1]
     assert any(ln.endswith("E") for ln in lines)                  # the loop ran to its validation at itr 8

@@ -133,7 +133,8 @@ def test_two_rank_trainer_equals_the_single_process_reference_loop(tmp_path):
         np.testing.assert_allclose([float(x) for x in fa[1:5]], [float(x) for x in fb[1:5]], rtol=1e-9)
     assert [os.path.basename(s)[:9] for s in saved0] == [os.path.basename(s)[:9] for s in ref.saved]
     assert sorted(os.listdir(base)) == sorted(["20", "40", "progress.csv", "vdata_train.npy"])
-    clip = np.load(base + "20/__0trans.npy")
+    from tests.test_trainer import read_clip
+    clip = read_clip(base + "20/__0trans.gif")
     assert clip.dtype == np.uint8 and clip.shape == (NLEN, H, W, 3)
     # the clip is rows 0..nlen-1 of the global batch: with B = 6 on two ranks they all live on rank 0 -- and at nlen = 3 = B / world
     # exactly; the gather through the all-reduce must reproduce what one process saves
@@ -145,7 +146,7 @@ def test_two_rank_trainer_equals_the_single_process_reference_loop(tmp_path):
                  log=lambda s: None).train()
     for kk in range(10):
         for tag in ("trans", "recon"):
-            np.testing.assert_array_equal(np.load(f"{base}40/__{kk}{tag}.npy"), np.load(f"{one}40/__{kk}{tag}.npy"))
+            np.testing.assert_array_equal(read_clip(f"{base}40/__{kk}{tag}.gif"), read_clip(f"{one}40/__{kk}{tag}.gif"))
 
 
 def test_trainer_refuses_bad_data_parallel_arguments(tmp_path):
