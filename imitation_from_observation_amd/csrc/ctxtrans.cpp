@@ -342,6 +342,10 @@ int dev_alloc(ctx_handle* h, T** p, int64_t count, bool whole_tensor = true) {
     if (e != hipSuccess) return fail(h, CTX_E_NOMEM, "hipMalloc(%lld bytes): %s", (long long)(count * sizeof(T)), hipGetErrorString(e));
     h->allocs.push_back(q);
     *p = (T*)q;
+    // debugging aid: CTX_DEBUG_POISON=1 fills every fresh buffer with 0xFF bytes (float NaN) so that a kernel reading memory nothing has
+    // written shows up as NaN on every run instead of as a rare mismatch that depends on what the allocator handed back
+    static const bool poison = getenv("CTX_DEBUG_POISON") && atoi(getenv("CTX_DEBUG_POISON"));
+    if (poison) (void)hipMemset(q, 0xFF, (size_t)count * sizeof(T));
     return CTX_OK;
 }
 

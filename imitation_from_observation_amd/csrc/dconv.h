@@ -64,6 +64,7 @@ struct DcFwd {
     int osc, hout, wout;                           // physical output grid
     int tiles_y, tiles_x;
     Epi ep;
+    unsigned long long* trace = nullptr;           // -DDC_TRACE builds of tools/dconv_bench.hip: s_memtime stamps [block][wave][tile][8] (never set by the product)
 };
 
 // LDS pixel stride of the input tile.  A fragment read is a ds_read_b128 at (S * CIP) * l15 + 4 * kg dwords; its four 16-lane
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void dconv_pack_kernel(const DcFwd P, int NP, 
         }
         P.wp[((int64_t)(ek >> 2) * NP + n) * 4 + (ek & 3)] = v;
     }
+    if (blockIdx.x == 0 && threadIdx.x < 16) P.wp[total + threadIdx.x] = 0.f;      // 64 bytes of zeros behind the image (dconv2.h: where halo lanes fetch from)
     (void)TPC;
 }
 
@@ -143,7 +145,11 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
         DcClass cl;                                          // (static indices: a dynamic one would put the argument struct in scratch)
         switch (ci) { case 0: cl = P.cls[0]; break; case 1: cl = P.cls[1]; break; case 2: cl = P.cls[2]; break; default: cl = P.cls[3]; break; }
         const int g0 = cl.pslot0 * CIK / 16, ng = (cl.ntaps + TPC - 1) / TPC * CPT;
-        for (int i = tid; i < (ng + 1) * 4; i += DC_THREADS) {           // (+ 1: the entry the pipeline reads one chunk ahead)
+        // (+ 1 behind the LAST class: the entry the pipeline reads ahead and never uses.  Behind the other classes that slot IS the next
+        // class's first entry -- writing a placeholder there raced with the thread that writes the real one: harmless while the
+        // placeholder's thread sat in wave 0 (classes of 4 / 6 taps first), wrong results on a cold box now and then once round 5 put
+        // the 9-tap class first and its placeholder into wave 1)
+        for (int i = tid; i < (ng + (ci == P.ncls - 1 ? 1 : 0)) * 4; i += DC_THREADS) {
             const int k16 = (i >> 2) * 16 + 4 * (i & 3);
             int e = k16 / CIK;
             const int kin = k16 - e * CIK;
@@ -216,6 +222,15 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
         }
     };
     auto land = [&](int t) {                                  // prefetch registers -> LDS tile
+        // (the empty asm pins the FIRST use of the prefetch registers here: land() sits inside the class loop, and loop-invariant code
+        // motion otherwise hoists the halo select -- and with it the s_waitcnt for the loads -- in front of the MFMA loops)
+        if constexpr (CIK == 4) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) asm volatile("" : "+v"(pf1[j]));
+        } else {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) asm volatile("" : "+v"(pf[j]));
+        }
         int iy = iyb, ix = ixb;
         if constexpr (CIK == 4) {
 #pragma unroll
@@ -262,15 +277,31 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
         ncol[nb] = P.n0 + nb * 16 + 4 * kg;
         bias_v[nb] = (P.ep.bias && ncol[nb] < P.N) ? ldg4(P.ep.bias + ncol[nb]) : zero4();
     }
+    // Order of a tile's phases (round 5):  issue(next) | MFMA loops of the classes | barrier | land(next) | stores of the last class |
+    // barrier.  The NEXT tile is written to LDS before this tile's results are stored: land() consumes the prefetch registers, i.e.
+    // waits for vmcnt(0) -- which also waits for every store issued before it.  With the stores in front of it (round 2-4: epilogue,
+    // drain, barrier, land) each tile paid a full store round trip (~1.4 us of 11: h1_conv forward 21 us of 170) with all eight
+    // waves idle; behind it, the stores retire under the next tile's MFMA loop.
     int t = blockIdx.x;
     if (t < ntiles) issue(t);
+    __syncthreads();                                         // (4th channel zeroed)
+    if (t < ntiles) land(t);
+    __syncthreads();                                         // tile, filter and offset table visible
+#ifdef DC_TRACE
+    int trace_i = 0;
+#define DC_STAMP(k) do { if (P.trace && lane == 0 && blockIdx.x < 8 && trace_i < 32) P.trace[(((size_t)blockIdx.x * DC_NW + wv) * 32 + trace_i) * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DC_STAMP(k) do {} while (0)
+#endif
     for (; t < ntiles; t += gridDim.x) {
-        __syncthreads();                                     // the previous tile's fragments are consumed (first pass: 4th channel zeroed)
-        land(t);
-        __syncthreads();                                     // tile (and, first pass, the filter) visible
-        if (t + (int)gridDim.x < ntiles) issue(t + gridDim.x);
+        const int tn = t + (int)gridDim.x;
+        DC_STAMP(0);
+#ifndef DC_ABL_NOLDG                                         // (ablation builds of tools/dconv_bench.hip only: wrong results, right amount of the OTHER work)
+        if (tn < ntiles) issue(tn);
+#endif
         int img, ty0, tx0;
         tile_org(t, img, ty0, tx0);
+        DC_STAMP(1);
 
         for (int ci = 0; ci < P.ncls; ++ci) {
             DcClass cl;                                      // (static indices: a dynamic one would put the argument struct in scratch)
@@ -306,23 +337,38 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) {
                                 const float bv = tt == 0 ? b4[buf][nb].x : tt == 1 ? b4[buf][nb].y : tt == 2 ? b4[buf][nb].z : b4[buf][nb].w;
+#ifdef DC_ABL_NOMFMA
+                                asm volatile("" :: "v"(bv), "v"(av));
+#else
                                 acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[mi][nb], 0, 0, 0);      // D^T: rows = channels, cols = pixels
+#endif
                             }
                         }
                     }
                 };
-                // software pipeline: fragments (and the table entry) of chunk g + 1 are read before the MFMAs of chunk g
+                // software pipeline: the fragments of chunk g + 1 are read before the MFMAs of chunk g, and the table entry of chunk
+                // g + 2 before them -- a fetch never waits for the table read in front of it (LDS returns in order: waiting for
+                // the newest read waits for all), and the scheduling barriers keep the compiler from sinking a fetch next to its use
+                // (it did, to save registers: the ISA had an s_waitcnt lgkmcnt(0) straight behind each ds_read_b128 -- the whole LDS
+                // latency exposed once per chunk, the MFMA loop at 65 % of its instruction count's time)
                 fetch(0);
                 int g = g0;
+                int tahead = tab[(g0 + 1) * 4 + kg];         // (the table has one entry past the class's last chunk)
                 for (; g + 2 < g1; g += 2) {
-                    tnext = tab[(g + 1) * 4 + kg];
+                    tnext = tahead;
+                    tahead = tab[(g + 2) * 4 + kg];
                     fetch(1);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(0);
-                    tnext = tab[(g + 2) * 4 + kg];
+                    __builtin_amdgcn_sched_barrier(0);
+                    tnext = tahead;
+                    tahead = tab[(g + 3) * 4 + kg];
                     fetch(0);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(1);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (g + 1 < g1) { tnext = tab[(g + 1) * 4 + kg]; fetch(1); mma(0); mma(1); }
+                if (g + 1 < g1) { tnext = tahead; fetch(1); __builtin_amdgcn_sched_barrier(0); mma(0); mma(1); }
                 else mma(0);
             };
             // The terms an element's epilogue needs from memory (skip-gradient adds, the saved activation behind lrelu') are requested
@@ -357,20 +403,38 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
                     }
                 }
             }
+#ifndef DC_ABL_NOLOOP
             if (wv + DC_NW * (MI - 1) < nrb) run(std::integral_constant<int, MI>{});
             else if constexpr (MI > 1) { if (active) run(std::integral_constant<int, MI - 1>{}); }
+#endif
+            if (ci == P.ncls - 1) {                          // the tile's last MFMA loop is done: every wave has read its last fragment
+                DC_STAMP(2);
+                __syncthreads();
+                DC_STAMP(3);
+#ifdef DC_ABL_NOLAND
+                if (false)
+#endif
+                if (tn < ntiles) land(tn);
+                DC_STAMP(4);
+            }
             // ---- epilogue of this class.  D^T: a lane has channels ncol[nb] .. + 3 of pixel x = l15 of each of its row blocks.  The
             // terms an element needs from memory (skip-gradient adds, the saved activation behind lrelu') are loaded for a whole row
             // block first, branch-free, and only then applied (epi_store's load -> wait -> store chain per element took
             // longer than the MFMA loop).
+#ifdef DC_ABL_NOEPI
+            if (acc[0][0][0] == 12345.678f) P.ep.out1[0] = acc[0][0][1];
+            if constexpr (false) {
+#else
             if constexpr (PRE) {
+#endif
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
-                    if (!pok[mi]) continue;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int n = ncol[nb];
-                        if (n >= P.N) continue;
+                        // (every loaded term is CONSUMED by every lane, whether it stores or not: a load whose use sits behind a branch
+                        // counts as possibly pending at the loop back-edge, and the compiler then puts s_waitcnt vmcnt(0) in front of the
+                        // next class's loads into the same registers -- i.e. waits for this class's stores and the next tile's prefetch)
                         float v[4] = {acc[mi][nb][0] + bias_v[nb].x, acc[mi][nb][1] + bias_v[nb].y, acc[mi][nb][2] + bias_v[nb].z, acc[mi][nb][3] + bias_v[nb].w};
                         if (P.ep.add1) { v[0] += p1[mi][nb].x; v[1] += p1[mi][nb].y; v[2] += p1[mi][nb].z; v[3] += p1[mi][nb].w; }
                         if (P.ep.add2) { v[0] += p2[mi][nb].x; v[1] += p2[mi][nb].y; v[2] += p2[mi][nb].z; v[3] += p2[mi][nb].w; }
@@ -379,18 +443,24 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lk * v[r]);
                         }
+                        if (P.ep.mask) {
+                            const bool m1 = n < P.ep.nsplit;
+                            v[0] *= (m1 && pm[mi][nb].x < 0.f) ? LEAK : 1.f; v[1] *= (m1 && pm[mi][nb].y < 0.f) ? LEAK : 1.f;
+                            v[2] *= (m1 && pm[mi][nb].z < 0.f) ? LEAK : 1.f; v[3] *= (m1 && pm[mi][nb].w < 0.f) ? LEAK : 1.f;
+                        }
+                        if (!pok[mi] || n >= P.N) continue;
                         if (n < P.ep.nsplit) {
-                            if (P.ep.mask) {
-                                v[0] *= pm[mi][nb].x >= 0.f ? 1.f : LEAK; v[1] *= pm[mi][nb].y >= 0.f ? 1.f : LEAK;
-                                v[2] *= pm[mi][nb].z >= 0.f ? 1.f : LEAK; v[3] *= pm[mi][nb].w >= 0.f ? 1.f : LEAK;
-                            }
                             *reinterpret_cast<float4*>(P.ep.out1 + ppix[mi] * P.ep.ld1 + n) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
                             *reinterpret_cast<float4*>(P.ep.out2 + ppix[mi] * P.ep.ld2 + (n - P.ep.nsplit)) = make_float4(v[0], v[1], v[2], v[3]);
                         }
                     }
                 }
-            } else {
+            } else
+#ifdef DC_ABL_NOEPI
+            if constexpr (false)
+#endif
+            {
                 int64_t pix[MI];
                 bool okp[MI];
 #pragma unroll
@@ -416,11 +486,9 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
                         for (int nb = 0; nb < NB; ++nb)
                             tm[nb] = ldg4(P.ep.mask + pix[mi] * P.ep.ldm + (ncol[nb] < P.N && ncol[nb] < P.ep.nsplit ? ncol[nb] : 0));
                     }
-                    if (!okp[mi]) continue;
 #pragma unroll
                     for (int nb = 0; nb < NB; ++nb) {
                         const int n = ncol[nb];
-                        if (n >= P.N) continue;
                         float v[4] = {acc[mi][nb][0] + bias_v[nb].x, acc[mi][nb][1] + bias_v[nb].y, acc[mi][nb][2] + bias_v[nb].z, acc[mi][nb][3] + bias_v[nb].w};
                         if (P.ep.add1) { v[0] += t1[nb].x; v[1] += t1[nb].y; v[2] += t1[nb].z; v[3] += t1[nb].w; }
                         if (P.ep.add2) { v[0] += t2[nb].x; v[1] += t2[nb].y; v[2] += t2[nb].z; v[3] += t2[nb].w; }
@@ -429,11 +497,13 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lk * v[r]);
                         }
+                        if (P.ep.mask) {                    // (every loaded term consumed by every lane: see the PRE form above)
+                            const bool m1 = n < P.ep.nsplit;
+                            v[0] *= (m1 && tm[nb].x < 0.f) ? LEAK : 1.f; v[1] *= (m1 && tm[nb].y < 0.f) ? LEAK : 1.f;
+                            v[2] *= (m1 && tm[nb].z < 0.f) ? LEAK : 1.f; v[3] *= (m1 && tm[nb].w < 0.f) ? LEAK : 1.f;
+                        }
+                        if (!okp[mi] || n >= P.N) continue;
                         if (n < P.ep.nsplit) {
-                            if (P.ep.mask) {
-                                v[0] *= tm[nb].x >= 0.f ? 1.f : LEAK; v[1] *= tm[nb].y >= 0.f ? 1.f : LEAK;
-                                v[2] *= tm[nb].z >= 0.f ? 1.f : LEAK; v[3] *= tm[nb].w >= 0.f ? 1.f : LEAK;
-                            }
                             *reinterpret_cast<float4*>(P.ep.out1 + pix[mi] * P.ep.ld1 + n) = make_float4(v[0], v[1], v[2], v[3]);
                         } else {
                             *reinterpret_cast<float4*>(P.ep.out2 + pix[mi] * P.ep.ld2 + (n - P.ep.nsplit)) = make_float4(v[0], v[1], v[2], v[3]);
@@ -441,14 +511,16 @@ __global__ __launch_bounds__(DC_THREADS, (PF <= DC_PF_SMALL ? 4 : 2)) void dconv
                     }
                 }
             }
-            // Every class ends with all of the wave's memory operations retired.  Without this the compiler's wait-count
-            // bookkeeping cannot prove, across the loop back-edges, that the epilogue's loads into registers the next fragment
-            // reads reuse are complete, and it puts an s_waitcnt vmcnt(0) in front of the first ds_read of the MFMA loop --
-            // i.e. it waits for the NEXT tile's prefetch right after issuing it (seen in the ISA; the prefetch then hid nothing).
-#ifndef DC_NO_DRAIN                                      // (A/B build of tools/dconv_bench.hip: the drain itself costs <= 2 %)
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0) only
+#ifdef DC_DRAIN                                          // (rounds 2-4 ended every class with s_waitcnt vmcnt(0): A/B build of tools/dconv_bench.hip)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
 #endif
         }
+        DC_STAMP(5);
+        __syncthreads();                                     // the next tile is visible
+        DC_STAMP(6);
+#ifdef DC_TRACE
+        ++trace_i;
+#endif
     }
 }
 

@@ -3,7 +3,9 @@
 #include <cstdlib>
 
 #include "dconv.h"
+#include "dconv2.h"
 #include "launch.h"
+#include "options.h"
 
 namespace ctx {
 
@@ -70,7 +72,141 @@ bool dconv_ok(int CI, int N) { return (CI == 3 || CI == 8 || CI == 16 || CI == 3
 // subject to: tile + resident filter <= LDS, tile elements <= 512 x DC_PF prefetch slots.  A filter too big to stay
 // resident beside any tile is run as several launches over column slices of 16 * NB (d_h3's input gradient in
 // ContextAEReal: 25 x 32 x 32 floats = 100 KB -> two slices of 16 columns).
+namespace {
+template <int NSL, int MI, bool NB2, int NCLS, int OCC>
+void launch_fwd2_one(hipStream_t s, const DcFwd& P, const DcFwd2& Q, dim3 grid, size_t lds, int ntiles, int nslots) {
+    ensure_dyn_lds((const void*)dconv_fwd2_kernel<NSL, MI, NB2, NCLS, OCC>, (size_t)LDS_TOTAL / OCC);
+    hipLaunchKernelGGL((dconv_fwd2_kernel<NSL, MI, NB2, NCLS, OCC>), grid, dim3(DC2_THREADS), lds, s, P, Q, ntiles, nslots);
+}
+constexpr int dc2_max_mi(int ncls) { return ncls == 4 ? 3 : 4; }        // units per wave: accumulators of every class live across the slices
+template <int NSL, bool NB2, int NCLS>
+bool launch_fwd2(hipStream_t s, const DcFwd& P, const DcFwd2& Q, int MI, int occ, dim3 grid, size_t lds, int ntiles, int nslots) {
+#define DC2_CASE(mi)                                                                                                     \
+    if constexpr (mi <= dc2_max_mi(NCLS)) {                                                                              \
+        if (MI == mi) {                                                                                                  \
+            (void)occ;                                                                                                   \
+            launch_fwd2_one<NSL, mi, NB2, NCLS, 1>(s, P, Q, grid, lds, ntiles, nslots);                                  \
+            return true;                                                                                                 \
+        }                                                                                                                \
+    }
+    DC2_CASE(1) DC2_CASE(2) DC2_CASE(3) DC2_CASE(4)
+#undef DC2_CASE
+    return false;
+}
+}  // namespace
+
+int g_dc2_last[5] = {0, 0, 0, 0, 0};   // TH, TW, units per wave, column blocks * 10 + occ, slices of the last dconv2 launch (0: the launch went to dconv_fwd_kernel)
+
+// The K-sliced, double-buffered LDS-DMA kernel of dconv2.h, for 16 / 32 input channels (either source split on a multiple of 4),
+// up to 32 filter columns in LDS beside two slice buffers, 1 or 4 tap classes.  false: not for this layer (the caller falls back).
+// Tile choice: a time model per tile on one CU --
+//   compute = MFMAs of the busiest SIMD (unit u -> compute wave u % 8 -> SIMD u % 4) x 37 cycles + fold and stores
+//   req     = DMA requests of a loader wave x 420 cycles;   dma = slice bytes / 24 B per clock
+//   T = max(compute, req, dma) + per-slice barrier and skew;   score = real output pixels per tile / T
+static bool dconv_launch2(hipStream_t s, DcFwd P, int span) {
+    if (!(opt(OPT_DCONV) & 2)) return false;
+    if ((P.CI != 16 && P.CI != 32) || P.N > 32 || (P.ncls != 1 && P.ncls != 4) || (P.c1 & 3) || (P.x2 && ((P.CI - P.c1) & 3))) return false;
+    // stride-2 transposed convs (four tap classes) stay on dconv_fwd_kernel unless bit 4 asks: their tiles store 4 x the pixels they read, the
+    // store path takes ~10 B / clk / CU whoever issues, and here the stores of ALL classes sit behind the closing barrier with the matrix
+    // pipe idle (measured: d_h3 forward 0.169 -> 0.200 ms, h1_conv dx 0.157 -> 0.195)
+    if (P.ncls == 4 && !(opt(OPT_DCONV) & 4)) return false;
+    if (P.ep.nsplit < P.N && (P.ep.nsplit & 3)) return false;
+    const int NSL = P.CI / 16, NBT = P.N > 16 ? 2 : 1, NP = NBT * 16;
+    int nslots = 0;
+    for (int c = 0; c < P.ncls; ++c) { P.cls[c].pslot0 = nslots; nslots += P.cls[c].ntaps; }
+    const size_t wall = (size_t)nslots * P.CI * NP * 4 + (size_t)(nslots + 1) * 4 + 16;
+    auto geo = [&](int th, int tw, int& ih, int& iw, int& iwp, int& iwh, size_t& slice) {
+        ih = P.S * (th - 1) + span; iw = P.S * (tw - 1) + span;
+        iwh = P.S == 2 ? (iw + 1) / 2 : 0;
+        iwp = P.S == 2 ? 2 * iwh : iw;
+        slice = ((size_t)ih * iwp * 16 + 255) / 256 * 256 * 4;            // bytes, whole 1 KB pieces
+    };
+    const int max_mi = dc2_max_mi(P.ncls);
+    int best_th = 0, best_tw = 0, best_mi = 0, best_occ = 1;
+    double best = -1;
+    for (int tw = 16; tw <= 64 && tw <= (P.wlog + 15) / 16 * 16; tw *= 2)
+        for (int th = 1; th <= 32; ++th) {
+            const int nunits = th * (tw / 16) * NBT, mi = (nunits + DC2_NCW - 1) / DC2_NCW;
+            if (mi > max_mi) break;
+            int ih, iw, iwp, iwh; size_t slice;
+            geo(th, tw, ih, iw, iwp, iwh, slice);
+            const size_t lds = 2 * slice + wall;
+            if (lds > (size_t)LDS_BUDGET) break;
+            int load[4] = {0, 0, 0, 0};
+            for (int u = 0; u < nunits; ++u) load[u & 3] += 1;             // unit u -> compute wave u % 8 -> SIMD u % 4
+            int busiest = 1;
+            for (int q = 0; q < 4; ++q) busiest = load[q] > busiest ? load[q] : busiest;
+            const int occ = 1;
+            const int tiles_y = (P.hlog + th - 1) / th, tiles_x = (P.wlog + tw - 1) / tw;
+            const double rows = (double)P.hlog * P.wlog / ((double)tiles_y * tiles_x);
+            // MFMA loops of a SIMD's two compute waves (85 % busy; a little less with one unit per wave: four MFMAs per LDS round trip) + fold and stores
+            const double compute = (double)busiest * 4.0 * nslots * NSL * (mi == 1 ? 40.0 : 37.0) + 250.0 * P.ncls * mi;
+            const double req = ((double)(slice / 1024 + 3) / 4 * 300.0 + 1500.0) * NSL;                  // DMA requests of a loader wave + the last one's latency
+            // ... and their bytes: a slice's DMA is LATENCY first (measured: ~7 k cycles for 30 KB with every CU loading -- the loaders
+            // have one slice in flight and nothing behind it), then ~11 B / clk / CU
+            const double dma = (5000.0 + (double)slice / 11.0) * NSL;
+            double T = compute > dma ? compute : dma;
+            if (req > T) T = req;
+            T += NSL * 700.0 / occ;                                                                       // barrier + skew per slice
+            const double score = rows / T;
+            if (score > best) { best = score; best_th = th; best_tw = tw; best_mi = mi; best_occ = occ; }
+        }
+    if (!best_th) return false;
+    if (const char* e = getenv("DC2_TILE")) {                                // measurement hook: "th,tw" for every dconv2 launch it fits
+        int th = 0, tw = 0;
+        if (sscanf(e, "%d,%d", &th, &tw) == 2 && th > 0 && (tw == 16 || tw == 32 || tw == 64)) {
+            int ih, iw, iwp, iwh; size_t slice;
+            geo(th, tw, ih, iw, iwp, iwh, slice);
+            const int mi = (th * (tw / 16) * NBT + DC2_NCW - 1) / DC2_NCW;
+            if (mi <= max_mi && 2 * slice + wall <= (size_t)LDS_BUDGET && tw <= (P.wlog + 15) / 16 * 16) { best_th = th; best_tw = tw; best_mi = mi; }
+        }
+    }
+    if (g_dc_force[0]) {
+        best_th = g_dc_force[0]; best_tw = g_dc_force[1];
+        int ih, iw, iwp, iwh; size_t slice;
+        geo(best_th, best_tw, ih, iw, iwp, iwh, slice);
+        const int nunits = best_th * (best_tw / 16) * NBT;
+        best_mi = (nunits + DC2_NCW - 1) / DC2_NCW;
+        g_dc2_last[0] = 0;
+        if (best_mi != g_dc_force[2] || best_mi > max_mi || 2 * slice + wall > (size_t)LDS_BUDGET) return true;   // (tile sweep of the bench: skip)
+        best_occ = 1;
+    }
+    P.TH = best_th; P.TW = best_tw;
+    DcFwd2 Q{};
+    size_t slice;
+    geo(P.TH, P.TW, P.IH, P.IW, Q.IWP, Q.IWH, slice);
+    Q.slice_floats = (int)(slice / 4);
+    Q.div_mul = (unsigned)(((1u << 20) + Q.IWP - 1) / Q.IWP);
+    for (int pi = 0; pi < Q.slice_floats / 16; ++pi)                       // the multiply-shift division must be exact on every pixel index
+        if ((int)(((unsigned)pi * Q.div_mul) >> 20) != pi / Q.IWP) return false;
+    P.CIP = 16;
+    P.tiles_y = (P.hlog + P.TH - 1) / P.TH;
+    P.tiles_x = (P.wlog + P.TW - 1) / P.TW;
+    P.NPT = NP; P.n0 = 0;
+    Q.zeros = P.wp + (size_t)nslots * P.CI * P.NPT;
+    const int ntiles = P.nimg * P.tiles_y * P.tiles_x;
+    const int slots = NUM_CU * best_occ;
+    const int rounds = (ntiles + slots - 1) / slots;
+    const dim3 grid((unsigned)((ntiles + rounds - 1) / rounds));
+    const size_t lds = 2 * slice + wall;
+    {
+        const int total = nslots * P.CI * P.NPT;
+        const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
+        if (P.CI == 16) hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, P.NPT, nslots);
+        else hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, P.NPT, nslots);
+    }
+    bool ok;
+#define DC2_GO(nsl, nb2, ncls) launch_fwd2<nsl, nb2, ncls>(s, P, Q, best_mi, best_occ, grid, lds, ntiles, nslots)
+    if (NSL == 1) ok = NBT == 1 ? (P.ncls == 1 ? DC2_GO(1, false, 1) : DC2_GO(1, false, 4)) : (P.ncls == 1 ? DC2_GO(1, true, 1) : DC2_GO(1, true, 4));
+    else ok = NBT == 1 ? (P.ncls == 1 ? DC2_GO(2, false, 1) : DC2_GO(2, false, 4)) : (P.ncls == 1 ? DC2_GO(2, true, 1) : DC2_GO(2, true, 4));
+#undef DC2_GO
+    if (ok) { g_dc2_last[0] = P.TH; g_dc2_last[1] = P.TW; g_dc2_last[2] = best_mi; g_dc2_last[3] = NBT * 10 + best_occ; g_dc2_last[4] = NSL; }
+    return ok;
+}
+
 static void dconv_launch(hipStream_t s, DcFwd P, int span) {
+    g_dc2_last[0] = 0;
+    if (dconv_launch2(s, P, span)) return;
     const int CIK = cik_of(P.CI), CIP = dc_cip(CIK, P.S);
     P.CIP = CIP;
     int NBT = (P.N + 15) / 16;
@@ -204,11 +340,12 @@ void dconv_convt2(hipStream_t s, DcFwd P) {
     P.hlog = P.hin; P.wlog = P.win; P.hout = 2 * P.hin; P.wout = 2 * P.win; P.osc = 2;
     P.ncls = 4;
     int nt = 0;
-    for (int c = 0; c < 4; ++c) {
+    for (int k = 0; k < 4; ++k) {
+        const int c = 3 - k;                                 // parity classes (1,1), (1,0), (0,1), (0,0): 9, 6, 6, 4 taps -- longest first (dconv2.h)
         const int py = c >> 1, px = c & 1;
         const int pary = (py + 1) & 1, parx = (px + 1) & 1, nty = (5 - pary + 1) / 2, ntx = (5 - parx + 1) / 2;
         const int oy = (py + 1 - pary) / 2, ox = (px + 1 - parx) / 2;
-        P.cls[c] = DcClass{nt, nty * ntx, py, px, 0, ntx, ntx == 2 ? 128 : 86, oy + 1, ox + 1, -1};
+        P.cls[k] = DcClass{nt, nty * ntx, py, px, 0, ntx, ntx == 2 ? 128 : 86, oy + 1, ox + 1, -1};
         for (int sy = 0; sy < nty; ++sy)
             for (int sx = 0; sx < ntx; ++sx)
                 P.taps[nt++] = DcTap{(int16_t)(oy - sy + 1), (int16_t)(ox - sx + 1), (int16_t)((pary + 2 * sy) * 5 + parx + 2 * sx), 0};

@@ -16,7 +16,8 @@ enum Opt {
     OPT_BALANCE,       // bits: 1 load-balanced problem order on <= 16-position grids, 2 on larger grids, 4 for the filter gradient's taps
     OPT_WCONVT,        // bits: 1 LDS-resident transposed conv (wconvt.hip), 2 row blocks on 4x4 grids, 4 row blocks on 8x8 grids, 8 column-uniform waves
     OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3)
-    OPT_DCONV,         // 1: ContextAEReal in f32 on the narrow-channel direct kernels (dconv.h)
+    OPT_DCONV,         // bits: 1 ContextAEReal in f32 on the narrow-channel direct kernels (dconv.h), 2 their forward-type launches on the K-sliced
+                       // double-buffered LDS-DMA kernel (dconv2.h) where it applies
     OPT_RCHAIN,        // 1: ContextAEReal's FC middle in three launches (rchain.hip)
     OPT_EARLY_ADAM,    // 1: Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms, round 4)
     OPT_CNN_LANES,     // Inception front end: -1 = by precision (lanes in split-bf16 mode only), 0 / 1 = off / on

@@ -126,7 +126,7 @@ const char* ctx_last_error(const ctx_handle* h);
  *   balance      3   bits: load-balanced problem order 1 on grids of <= 16 positions, 2 on larger grids, 4 for the filter gradient's taps
  *   wconvt      15   bits: 1 LDS-resident transposed conv, 2 / 4 row blocks on 4x4 / 8x8 grids, 8 column-uniform waves (4x4)
  *   direct3     15   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass  [fixed at create]
- *   dconv        1   ContextAEReal in f32 on the narrow-channel direct kernels                                          [fixed at create]
+ *   dconv        3   bits: 1 ContextAEReal in f32 on the narrow-channel direct kernels, 2 the K-sliced LDS-DMA forward kernel     [fixed at create]
  *   rchain       1   ContextAEReal's FC middle in three launches
  *   early_adam   1   Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms)
  *   cnn_lanes   -1   Inception front end: branch lanes; -1 = in the split-bf16 mode only      (ctx_cnn handles: environment at create) [fixed at create]

@@ -60,6 +60,17 @@ def test_real_forward_backward_matches_oracle(T, H, W, B):
         sc = tr.train_step(src, ctx, tgt, lr=0.0)
         assert abs(sc["loss"] - res["loss"]) <= 1e-5 * abs(res["loss"])
         gg = tr.get_grads()
+        if W % 64 == 0:
+            # lrelu is not differentiable at 0: an activation within f32 rounding of zero may land on the other side than in float64 (seen at
+            # 20x128: ONE element of e1 at 2.8e-8 of the tensor's max, which moved every gradient upstream of d_h1 by up to 8e-3 when the
+            # K-sliced kernel of dconv2.h changed the summation order).  The oracle differentiates on the device's branch at exactly those
+            # elements -- counted and bounded (tests/_align.py; the narrow path keeps the real channel widths its buffers are read with).
+            from tests._align import align_gen_cache
+            nflip, worst, where = align_gen_cache(tr, c, B)
+            assert nflip <= 8 and worst <= 1e-6, (nflip, worst, where)
+            if nflip:
+                print(f"{H}x{W}: aligned {nflip} activations (|x| / max|x| <= {worst:.1e}) in {where}")
+                g = r.backward(p, c, cfg)
         for n in g:
             assert relmax(gg[n], g[n]) < 1e-4, n
         # inference call sites (base.py:216-218, 234-235)

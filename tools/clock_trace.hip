@@ -4,7 +4,8 @@
 // s_memrealtime (constant 100 MHz) at its first and last instruction: effective clock of that launch = d(memtime) / d(realtime) * 100 MHz.
 // Launches of ~4 ms are repeated back to back for SECONDS seconds per body, so the table shows the clock settling under
 // sustained load.  Bodies:
-//   mfma32     nothing but v_mfma_f32_32x32x2_f32, four independent accumulators per wave, 8 waves per CU   (tools/peaks.hip's loop)
+//   mfma32     nothing but v_mfma_f32_32x32x2_f32, four independent accumulators per wave, 8 waves per CU   (tools/peaks.hip's loop,
+//              but on RANDOM operands that change from one MFMA to the next)
 //   mfma16     the same with v_mfma_f32_16x16x4_f32 (the direct kernels' instruction)
 //   mfma32+ld  the MFMA stream with, per 8 MFMAs, two 16-byte global loads (L2-resident 8 MB window), two ds_write_b128 and four
 //              ds_read_b128 per lane -- the operand feed of an implicit-GEMM step, results folded into the MFMA operands
@@ -23,21 +24,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Stamp { uint64_t c0, c1, r0, r1; };
 
+__global__ void fill_random(float* p, int64_t n) {          // values in [-1, 1)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        p[i] = (float)(int)(h & 0xFFFF) * (1.f / 32768.f) - 1.f;
+    }
+}
+
 template <int BODY>
 __global__ __launch_bounds__(512) void body_kernel(Stamp* st, const float4* __restrict__ src, int64_t n4, int iters, float* sink) {
     __shared__ float4 lds[512 * 2];
     const int tid = threadIdx.x;
     uint64_t c0 = 0, r0 = 0;
     if (tid == 0) { c0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
-    float x = 1.0f + tid * 1e-6f, y = 1.0f - tid * 1e-6f;
+    // RANDOM operands, four different ones per lane in rotation: the matrix pipe's inputs toggle from one MFMA to the next as they do
+    // on real activations (constant operands draw less power and hold a higher clock -- MI355X_MICROARCH.md, "DVFS give-back")
+    auto rnd = [&](unsigned k) { unsigned h = (blockIdx.x * 512u + tid) * 2654435761u + k * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; return (float)(int)(h & 0xFFFF) * (1.f / 32768.f) - 1.f; };
+    float x = rnd(1), y = rnd(2), z = rnd(3), w = rnd(4);
     float s = 0.f;
     if constexpr (BODY == 1) {
         f32x4 a0 = {}, a1 = {}, a2 = {}, a3 = {}, a4 = {}, a5 = {}, a6 = {}, a7 = {};
         for (int i = 0; i < iters; ++i) {
-            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, y, a3, 0, 0, 0);
-            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a4, 0, 0, 0); a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, x, a5, 0, 0, 0);
-            a6 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, x, a6, 0, 0, 0); a7 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, y, a7, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(z, w, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, z, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, x, a3, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f32_16x16x4f32(x, z, a4, 0, 0, 0); a5 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, w, a5, 0, 0, 0);
+            a6 = __builtin_amdgcn_mfma_f32_16x16x4f32(z, x, a6, 0, 0, 0); a7 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, y, a7, 0, 0, 0);
         }
         for (int r = 0; r < 4; ++r) s += a0[r] + a1[r] + a2[r] + a3[r] + a4[r] + a5[r] + a6[r] + a7[r];
     } else {
@@ -51,15 +62,15 @@ __global__ __launch_bounds__(512) void body_kernel(Stamp* st, const float4* __re
                     idx += step; if (idx >= n4) idx -= n4;
                     lds[tid] = u; lds[512 + tid] = v;
                     __syncthreads();
-                    const float4 p = lds[(tid + 64) & 511], q = lds[512 + ((tid + 128) & 511)], r = lds[(tid + 192) & 511], w = lds[512 + ((tid + 256) & 511)];
-                    x += (p.x + q.y) * 1e-30f; y += (r.z + w.w) * 1e-30f;
+                    const float4 p = lds[(tid + 64) & 511], q = lds[512 + ((tid + 128) & 511)], r = lds[(tid + 192) & 511], ww = lds[512 + ((tid + 256) & 511)];
+                    x = x * 0.5f + (p.x + q.y) * 0.25f; y = y * 0.5f + (r.z + ww.w) * 0.25f;
                     __syncthreads();
                 }
             }
             a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
-            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
-            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(z, w, a1, 0, 0, 0);
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, z, a2, 0, 0, 0);
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, x, a3, 0, 0, 0);
         }
         for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
     }
@@ -109,7 +120,7 @@ int main(int argc, char** argv) {
     printf("%s, %d CUs, clockRate %d kHz\n", pr.name, blocks, pr.clockRate);
     const int64_t small = 8ll << 20, big = 2ll << 30;
     float4* buf; if (hipMalloc((void**)&buf, big) != hipSuccess) return 1;
-    (void)hipMemset(buf, 0, big);
+    fill_random<<<4096, 256>>>(reinterpret_cast<float*>(buf), big / 4);
     const double f32 = 8.0 * 4 * (2.0 * 32 * 32 * 2), f16 = 8.0 * 8 * (2.0 * 16 * 16 * 4);
     run<0>("mfma32", seconds, blocks, buf, small / 16, 36000, f32);
     run<1>("mfma16", seconds, blocks, buf, small / 16, 36000, f16);

@@ -9,10 +9,14 @@
 #include <vector>
 
 #include "launch.h"
+#include "options.h"
+#include <cmath>
+#include <algorithm>
 
 namespace ctx {
 void dconv_force_tile(int th, int tw, int mi);
 extern int g_dc_last[4];
+extern int g_dc2_last[5];
 }
 using namespace ctx;
 
@@ -29,6 +33,7 @@ static float* dalloc(size_t n, float val) {
 
 int main(int argc, char** argv) {
     const int only = argc > 1 ? atoi(argv[1]) : -1;      // one layer, automatic tile, three launches: for rocprofv3 --pmc
+    const bool auto_only = getenv("DCB_AUTO_ONLY") != nullptr;   // no tile sweep: the automatic choice of every layer (ablation builds)
     const int B = 256;
     const Layer layers[] = {
         {"h0 fwd      F s1  3->32  36x64 x768", 0, 3, 3, 3 * B, 36, 64, 1, 32},
@@ -85,13 +90,68 @@ int main(int argc, char** argv) {
         const int hl = L.kind == 0 ? L.hin / L.S : L.hin, wl = L.kind == 0 ? L.win / L.S : L.win;
         const double flops = 2.0 * L.nimg * (L.kind == 2 ? 4.0 * hl * wl * 6.25 : (double)hl * wl * 25) * L.CI * L.N;
         dconv_force_tile(0, 0, 0);
+        if (getenv("DCB_VERIFY")) {   // dconv2 against dconv_fwd_kernel on the same operands, many launches: a race detector
+            const size_t nout = (size_t)L.nimg * (L.kind == 2 ? 4 : 1) * hl * wl * L.N;
+            std::vector<float> ref(nout), got(nout);
+            Options o1 = options_from_env(); o1.v[OPT_DCONV] = 1;
+            Options o3 = options_from_env(); o3.v[OPT_DCONV] = 7;
+            (void)hipMemset(out, 0, nout * 4);
+            { OptScope os(&o1); run(); }
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(ref.data(), out, nout * 4, hipMemcpyDeviceToHost);
+            int bad_runs = 0; double worst = 0; size_t worst_n = 0;
+            const int reps = atoi(getenv("DCB_VERIFY")) > 0 ? atoi(getenv("DCB_VERIFY")) : 20;
+            static hipStream_t hog = nullptr; static char* hb = nullptr;
+            if (getenv("DCB_HOG") && !hog) { (void)hipStreamCreate(&hog); (void)hipMalloc(&hb, 2ull << 30); }
+            for (int r = 0; r < reps; ++r) {
+                (void)hipMemset(out, 0, nout * 4);
+                if (hog) for (int k = 0; k < 4; ++k) (void)hipMemcpyAsync(hb, hb + (1ull << 30), 1ull << 30, hipMemcpyDeviceToDevice, hog);   // memory traffic beside the launch
+                { OptScope os(&o3); run(); }
+                (void)hipStreamSynchronize(st);
+                if (hog) (void)hipStreamSynchronize(hog);
+                (void)hipMemcpy(got.data(), out, nout * 4, hipMemcpyDeviceToHost);
+                double mx = 0, sc = 0; size_t nb = 0, first = 0;
+                for (size_t i = 0; i < nout; ++i) { sc = std::max(sc, (double)fabsf(ref[i])); }
+                for (size_t i = 0; i < nout; ++i) { const double d = fabs((double)got[i] - ref[i]); if (d > 1e-4 * sc) { if (!nb) first = i; ++nb; } mx = std::max(mx, d); }
+                if (nb) { ++bad_runs; if (nb > worst_n) worst_n = nb; printf("   run %d: %zu elements off (first at %zu = pixel %zu ch %zu), max |d| / max|ref| %.2e\n", r, nb, first, first / L.N, first % L.N, mx / sc); }
+                worst = std::max(worst, mx / sc);
+            }
+            printf("%s  verify: %d of %d launches differ from dconv_fwd_kernel (worst %.2e, up to %zu elements)  [dconv2 tile TH %d TW %d]\n", L.name, bad_runs, reps, worst, worst_n, g_dc2_last[0], g_dc2_last[1]);
+            continue;
+        }
+#ifdef DC_TRACE
+        {   // phase stamps of blocks 0..7, all waves, the first 32 tiles each: mean duration of each phase in shader cycles
+            unsigned long long* tr;
+            const size_t nst = (size_t)8 * 8 * 32 * 8;
+            (void)hipMalloc(&tr, nst * 8); (void)hipMemset(tr, 0, nst * 8);
+            run(); (void)hipStreamSynchronize(st);
+            P.trace = tr; run(); (void)hipStreamSynchronize(st); P.trace = nullptr;
+            std::vector<unsigned long long> h(nst);
+            (void)hipMemcpy(h.data(), tr, nst * 8, hipMemcpyDeviceToHost);
+            const char* nm1[7] = {"issue", "classes(loops+mid epilogues)", "barrier A", "land", "epilogue(last)", "barrier B", "tile total"};
+            const char* nm2[7] = {"pre+DMA requests", "MFMA loops+fold", "wait DMA", "barrier", "stores", "-", "LAST SLICE total"};
+            const char** nm = g_dc2_last[0] ? nm2 : nm1;
+            double sum[7] = {}; int n = 0;
+            for (int b = 0; b < 8; ++b) for (int w = 0; w < 8; ++w) for (int i = 1; i < 31; ++i) {   // (dconv2: the compute waves)
+                const unsigned long long* s = &h[(((size_t)b * 8 + w) * 32 + i) * 8];
+                if (!s[0] || !s[6]) continue;
+                for (int k = 0; k < 6; ++k) sum[k] += (double)(s[k + 1] - s[k]);
+                sum[6] += (double)(s[6] - s[0]); ++n;
+            }
+            printf("%s  phases (cycles, mean over %d wave-tiles):", L.name, n);
+            for (int k = 0; k < 7; ++k) printf("  %s %.0f", nm[k], n ? sum[k] / n : 0.0);
+            printf("\n");
+            (void)hipFree(tr);
+        }
+#endif
         if (only >= 0) { run(); run(); run(); (void)hipStreamSynchronize(st); continue; }
         const float t_auto = timeit();
-        printf("%s  auto: TH %d TW %d MI %d NB*10+occ %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
+        if (g_dc2_last[0]) printf("%s  dconv2: TH %d TW %d MI %d NB*10+occ %d slices %d  %.3f ms  %.1f TF/s\n", L.name, g_dc2_last[0], g_dc2_last[1], g_dc2_last[2], g_dc2_last[3], g_dc2_last[4], t_auto, flops / t_auto / 1e9);
+        else printf("%s  auto: TH %d TW %d MI %d NB*10+occ %d  %.3f ms  %.1f TF/s\n", L.name, g_dc_last[0], g_dc_last[1], g_dc_last[2], g_dc_last[3], t_auto,
                flops / t_auto / 1e9);
         struct R { int th, tw, mi; float ms; };
         std::vector<R> rs;
-        for (int tw = 16; tw <= 64; tw *= 2) {
+        for (int tw = 16; tw <= 64 && !auto_only; tw *= 2) {
             if (tw > (wl + 15) / 16 * 16) continue;
             for (int mi = 1; mi <= 4; ++mi)
                 for (int th = 1; th <= 16; ++th) {
