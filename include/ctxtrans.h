@@ -135,7 +135,9 @@ const char* ctx_last_error(const ctx_handle* h);
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
  *   adam_prio    2   HIP priority of the early-Adam stream (1 low: its own hardware queue; 0 normal; -1 high; 2 = low for exact-f32 handles,
  *                    normal for split-bf16 ones, reads back resolved)  [fixed at create]
- * Results never depend on a switch beyond f32 summation order.  Not options: CTX_RCCL_LIB (path of the librccl to dlopen, read by the
+ * Results never depend on a switch beyond f32 summation order.  Not options: CTX_DEBUG_POISON=1 (debugging aid: every device
+ * buffer a handle allocates is filled with 0xFF bytes -- float NaN -- so that a read of never-written memory shows on every run),
+ * CTX_RCCL_LIB (path of the librccl to dlopen, read by the
  * first ctx_dp_* call of the process). */
 int ctx_option_count(void);
 const char* ctx_option_name(int index);                               /* NULL past the end */

@@ -112,7 +112,8 @@ def test_result_pool_recycles_only_released_arrays():
 
 def test_options_are_enumerable_and_documented(built_lib):
     """Every per-handle switch the library knows (ctx_option_count / ctx_option_name) is documented in include/ctxtrans.h, and no
-    other CTX_* environment variable is read by the kernels' sources (only CTX_RCCL_LIB, the dlopen path)."""
+    other CTX_* environment variable is read by the kernels' sources (only CTX_RCCL_LIB, the dlopen path, and the debugging aid
+    CTX_DEBUG_POISON, which fills fresh device buffers with NaN)."""
     import glob
     import re
     names = [built_lib.ctx_option_name(i).decode() for i in range(built_lib.ctx_option_count())]
@@ -125,4 +126,5 @@ def test_options_are_enumerable_and_documented(built_lib):
     for f in glob.glob(os.path.join(ROOT, "imitation_from_observation_amd", "csrc", "*")):
         if f.endswith((".hip", ".h", ".cpp", ".inc")):
             env |= set(re.findall(r'getenv\("(CTX_[A-Z0-9_]+)"\)', open(f).read()))
-    assert env == {"CTX_RCCL_LIB"}, env
+    assert env == {"CTX_RCCL_LIB", "CTX_DEBUG_POISON"}, env
+    assert "CTX_DEBUG_POISON" in header
