@@ -654,7 +654,42 @@ __global__ __launch_bounds__(NTHREADS) void colsum_final_kernel(const float* __r
     }
 }
 
+// few rows (the 1x1 / 2x2 feature maps of ContextAEInception2 at 64 triples: 128-512 rows of 512-2048 columns): ONE launch -- 16 float4
+// columns x 16 row lanes per block, the lanes combined in fixed order through LDS.  The two-stage form above is two ~4.7 us launches
+// for a few hundred KB, 38 of them per step (0.18 of config 4's 2.6 ms translator share).
+__global__ __launch_bounds__(NTHREADS) void colsum_small_kernel(const float* __restrict__ x, int rows, int C, float* __restrict__ out) {
+    __shared__ float4 sh[16][16];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c4 = blockIdx.x * 16 + cq;
+    float4 acc = zero4();
+    if (c4 * 4 < C) {
+        const float* px = x + c4 * 4;
+        int r = rl;
+        for (; r + 48 < rows; r += 64) {                    // four loads in flight, summed in row order
+            const float4 v0 = ldg4(px + (int64_t)r * C), v1 = ldg4(px + (int64_t)(r + 16) * C), v2 = ldg4(px + (int64_t)(r + 32) * C), v3 = ldg4(px + (int64_t)(r + 48) * C);
+            acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+            acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+            acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+            acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+        }
+        for (; r < rows; r += 16) {
+            const float4 v = ldg4(px + (int64_t)r * C);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    sh[rl][cq] = acc;
+    __syncthreads();
+    if (rl == 0 && c4 * 4 < C) {
+        for (int k = 1; k < 16; ++k) { const float4 v = sh[k][cq]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        *reinterpret_cast<float4*>(out + c4 * 4) = acc;
+    }
+}
+
 void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, float* out) {
+    if (C != 3 && (C & 3) == 0 && rows <= 1024) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((C / 4 + 15) / 16), dim3(NTHREADS), 0, s, x, (int)rows, C, out);
+        return;
+    }
     if (C == 3) {                                          // rows is a multiple of 4 (H, W multiples of 16)
         const int64_t n12 = rows / 4;
         int nsl = (int)((n12 + NTHREADS * 8 - 1) / (NTHREADS * 8));
