@@ -93,6 +93,7 @@ SIGNATURES = {
     "ctx_last_outputs": (_c.c_int, [_P, _F, _F, _F]),
     "ctx_eval": (_c.c_int, [_P, _F, _F, _F, _c.c_int, _F, _F, _F]),
     "ctx_dev_forward_backward": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_int]),
+    "ctx_dev_frames": (_c.c_int, [_P, _c.c_int, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_void_p)]),
     "ctx_dev_forward": (_c.c_int, [_P, _P, _P, _P, _c.c_int]),
     "ctx_dev_train_step": (_c.c_int, [_P, _P, _P, _P, _c.c_int, _c.c_float]),
     "ctx_set_grad_bucket_callback": (_c.c_int, [_P, _P, _P]),

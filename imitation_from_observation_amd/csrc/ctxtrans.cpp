@@ -1506,18 +1506,34 @@ int ctx_reward_costs(ctx_handle* h, int vp, const uint8_t* frames, int npaths, f
     return finish(h);
 }
 
+// d_src / d_ctx / d_tgt -> the handle's frame buffer [tgt | src | ctx]; a slot the caller filled IN PLACE (pointers of ctx_dev_frames) is not copied
+static int stage_frames(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B) {
+    const size_t bytes = (size_t)B * h->npi * sizeof(float);
+    const float* from[3] = {d_tgt, d_src, d_ctx};
+    for (int k = 0; k < 3; ++k) {
+        float* slot = h->img + (int64_t)k * B * h->npi;
+        if (from[k] != slot) HIP_TRY(h, hipMemcpyAsync(slot, from[k], bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return CTX_OK;
+}
+
 int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt, int B) {
     TRY(check_B(h, B));
     if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)B * h->npi * sizeof(float);
-    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    TRY(stage_frames(h, d_src, d_ctx, d_tgt, B));
     forward(h, B, MODE_TRAIN);
     losses(h->stream, h->out, h->img, nullptr, h->npi, B, h->Z, h->Z + (int64_t)B * h->Fp, nullptr, h->Fp, B, h->scratch, h->scalars, h->F, loss_terms_of(h));
     h->last_B = B;
     HIP_TRY(h, hipGetLastError());
+    return CTX_OK;
+}
+
+int ctx_dev_frames(ctx_handle* h, int B, float** d_src, float** d_ctx, float** d_tgt) {
+    TRY(check_B(h, B));
+    if (d_tgt) *d_tgt = h->img;
+    if (d_src) *d_src = h->img + (int64_t)B * h->npi;
+    if (d_ctx) *d_ctx = h->img + 2ll * B * h->npi;
     return CTX_OK;
 }
 
@@ -1526,10 +1542,7 @@ int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_c
     if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
     if (sim_batch < 0) return fail(h, CTX_E_INVALID, "sim_batch < 0");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)B * h->npi * sizeof(float);
-    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    TRY(stage_frames(h, d_src, d_ctx, d_tgt, B));
     h->drop_on = true;      // (dropout belongs to the training graph only)
     forward(h, B, MODE_TRAIN);
     backward(h, B, sim_batch ? sim_batch : B);
@@ -1543,10 +1556,7 @@ int ctx_dev_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, co
     TRY(check_B(h, B));
     if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)B * h->npi * sizeof(float);
-    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    TRY(stage_frames(h, d_src, d_ctx, d_tgt, B));
     TRY(fused_step(h, B, lr));
     h->last_B = B;
     { char msg[256]; if (take_launch_error(msg, sizeof msg)) return fail(h, CTX_E_DEVICE, "%s", msg); }
@@ -1832,10 +1842,7 @@ int ctx_dp_train_step(ctx_handle* h, const float* d_src, const float* d_ctx, con
     if (!h->dp_comm) return fail(h, CTX_E_STATE, "ctx_dp_init first");
     if (!d_src || !d_ctx || !d_tgt) return fail(h, CTX_E_INVALID, "NULL input");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)B * h->npi * sizeof(float);
-    HIP_TRY(h, hipMemcpyAsync(h->img, d_tgt, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + B * h->npi, d_src, bytes, hipMemcpyDeviceToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(h->img + 2 * B * h->npi, d_ctx, bytes, hipMemcpyDeviceToDevice, h->stream));
+    TRY(stage_frames(h, d_src, d_ctx, d_tgt, B));
     return dp_step_on_img(h, B, lr, scalars);
 }
 

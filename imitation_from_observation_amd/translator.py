@@ -460,6 +460,13 @@ class Translator:
         self._ck(self._lib.ctx_dev_forward_backward(self._h, ctypes.c_void_p(d_src), ctypes.c_void_p(d_ctx),
                                                      ctypes.c_void_p(d_tgt), B, sim_batch))
 
+    def dev_frames(self, B):
+        """(d_src, d_ctx, d_tgt): integer device addresses of the handle's OWN frame slots for a batch of B.  A caller that writes its
+        frames there and passes these addresses to dev_forward_backward / dev_train_step / dp_train_step saves the 3 B-frame copy."""
+        ps = [ctypes.c_void_p() for _ in range(3)]
+        self._ck(self._lib.ctx_dev_frames(self._h, B, *(ctypes.byref(p) for p in ps)))
+        return tuple(int(p.value) for p in ps)
+
     def dev_train_step(self, d_src, d_ctx, d_tgt, B, lr=1e-4):
         """One whole training step (forward + backward + Adam) on device-resident frames, asynchronous on the handle's stream:
         bit-identical to dev_forward_backward + dev_adam, with Adam's slices enqueued beside the remaining backward."""

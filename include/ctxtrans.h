@@ -40,8 +40,8 @@
 extern "C" {
 #endif
 
-#define CTX_ABI_VERSION 3   /* 2: ctx_config carries strides / kernels / filters / keep_prob / loss_mode; 3: per-handle options,
-                               ctx_dp_train_step_sampled / ctx_dp_eval_sampled, ctx_prof_entry.useful_frac */
+#define CTX_ABI_VERSION 4   /* 2: ctx_config carries strides / kernels / filters / keep_prob / loss_mode; 3: per-handle options,
+                               ctx_dp_train_step_sampled / ctx_dp_eval_sampled, ctx_prof_entry.useful_frac; 4: ctx_dev_frames */
 
 enum {
     CTX_OK = 0,
@@ -233,6 +233,10 @@ int ctx_eval(ctx_handle* h, const float* src, const float* ctx, const float* tgt
  * full-batch gradient. */
 int ctx_dev_forward_backward(ctx_handle* h, const float* d_src, const float* d_ctx,
                              const float* d_tgt, int B, int sim_batch);
+/* The handle's own frame buffer for a batch of B: the device entry points (ctx_dev_*, ctx_dp_train_step) copy the caller's three
+ * tensors into it (3 B frames device-to-device per step) -- unless a pointer passed to them IS the one returned here, i.e. the caller
+ * (a device-side sampler, a front end) wrote that slot in place.  The pointers depend on B (slots are packed [tgt | src | ctx]). */
+int ctx_dev_frames(ctx_handle* h, int B, float** d_src, float** d_ctx, float** d_tgt);
 int ctx_dev_forward(ctx_handle* h, const float* d_src, const float* d_ctx, const float* d_tgt,
                     int B);
 /* One whole training step on device-resident frames: forward + backward + Adam (train_script.py:163's

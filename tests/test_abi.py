@@ -29,7 +29,7 @@ def test_ctypes_table_matches_header(built_lib, repo_root):
 
 
 def test_abi_version(built_lib):
-    assert built_lib.ctx_abi_version() == 3
+    assert built_lib.ctx_abi_version() == 4
 
 
 def test_param_total_is_the_references(built_lib):

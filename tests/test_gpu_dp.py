@@ -94,3 +94,39 @@ def test_rccl_behind_the_c_abi_on_one_rank():
         np.testing.assert_array_equal(tr.translator.get_params_flat(), ref.get_params_flat())
         np.testing.assert_array_equal(ph.get_params_flat(), ref.get_params_flat())
     tr.translator.close()
+
+
+@pytest.mark.gpu
+def test_frames_written_in_place_skip_the_staging_copy():
+    """ctx_dev_frames (ABI 4): a caller that writes its shard straight into the handle's [tgt | src | ctx] slots and
+    passes those pointers to ctx_dev_forward_backward / ctx_dev_train_step gets bit for bit what the copying path gives -- and a
+    pointer that is NOT the slot is still copied (mixed: only ctx in place)."""
+    import ctypes
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from imitation_from_observation_amd import Translator
+    H = W = 32
+    B = 6
+    g = torch.Generator(device="cuda").manual_seed(5)
+    fr = [torch.rand((B, H, W, 3), device="cuda", generator=g) * 2 - 1 for _ in range(3)]      # src, ctx, tgt
+    torch.cuda.synchronize()
+    with Translator(H, W, 32, 128, max_batch=8) as a, Translator(H, W, 32, 128, max_batch=8) as b:
+        a.init_params(3)
+        b.set_params_flat(a.get_params_flat())
+        a.dev_forward_backward(*(t.data_ptr() for t in fr), B)
+        a.sync()
+        slots = b.dev_frames(B)
+        assert len(set(slots)) == 3 and b.dev_frames(B - 1) != slots                        # packed per batch size
+        hip = ctypes.CDLL("libamdhip64.so")
+        for dst, t in zip(slots, fr):
+            assert hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(t.data_ptr()), ctypes.c_size_t(t.numel() * 4), 3) == 0   # hipMemcpyDeviceToDevice
+        b.dev_forward_backward(*slots, B)
+        b.sync()
+        np.testing.assert_array_equal(a.get_grads_flat(), b.get_grads_flat())
+        assert a.dev_scalars() == b.dev_scalars()
+        # mixed: src and tgt from the caller's tensors (copied), ctx in place
+        b.dev_train_step(fr[0].data_ptr(), slots[1], fr[2].data_ptr(), B, lr=1e-3)
+        a.dev_train_step(*(t.data_ptr() for t in fr), B, lr=1e-3)
+        a.sync(); b.sync()
+        np.testing.assert_array_equal(a.get_params_flat(), b.get_params_flat())
