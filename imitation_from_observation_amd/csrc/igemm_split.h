@@ -24,6 +24,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // (x0, x1) -> packed bf16 pairs hi, lo  (element 0 in the low half)
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+#ifdef CTX_ABL_SPLIT_NOCVT      // timing ablation only (WRONG numbers): the staging cost of operands that arrive pre-split -- same bytes, no conversion
+    hi = __float_as_uint(x0); lo = __float_as_uint(x1);
+    return;
+#endif
     const f32x2 v = {x0, x1};
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
     const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
