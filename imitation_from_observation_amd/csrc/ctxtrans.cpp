@@ -99,6 +99,8 @@ struct ctx_handle {
     bool overlap = true;
     // hipGraph cache of the two inference forwards (reward hook: batch-25 calls are launch-bound): key = mode * 2^20 + B
     struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; };
+    bool ctx_single = false;         // MODE_TRANSLATE with ONE context frame for the whole batch (`[context] * batch_size`, base.py:217-218):
+                                     // `conv_context` runs on that one frame and its outputs are read by every row (forward)
     std::map<int, GraphSlot> graphs;
     bool use_graphs = true, capturing = false;
     // data-parallel overlap: called from inside backward once the translate/* and deconv/* gradients are complete in the
@@ -115,6 +117,7 @@ struct ctx_handle {
     std::vector<RewardCache> rcache;
     float* rcosts = nullptr;
     float* P3 = nullptr;   // d_h4 scatter product [2B * H/2 * W/2][P3_LD]
+    float* PP = nullptr;   // transposed-conv product of the starved inference launches (<= PP_IMG images): [images * hs * ws][25 ca], largest layer
     int64_t slab_floats = 0;
     // data parallel over RCCL (ctx_dp_*): communicator, a stream for the collectives (they overlap the encoders' backward),
     // the events that order it with the compute stream, a device buffer for the global scalars
@@ -389,8 +392,13 @@ int alloc_buffers(ctx_handle* h) {
     }
     TRY(dev_alloc(h, &h->out, 2 * B * h->npi));
     // d_h4's scatter product exists only where the direct 3-channel kernel (convt3.hip) does not run: the split-bf16 mode / odd shapes
-    if (!d_h4_direct(h, d, d, h->hh[1], h->ww[1], 2))
-        TRY(dev_alloc(h, &h->P3, 2 * B * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
+    // (a handle on the direct kernel keeps a small one for the starved inference launches, which take the product + gather route: forward)
+    TRY(dev_alloc(h, &h->P3, (d_h4_direct(h, d, d, h->hh[1], h->ww[1], 2) ? std::min<int64_t>(B, PP_IMG) : 2 * B) * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
+    {   // (option "wconvt" bit 16)
+        int64_t per = 0;
+        for (int k = 1; k <= 3; ++k) per = std::max<int64_t>(per, (int64_t)h->hh[5 - k] * h->ww[5 - k] * 25 * ((8 * d) >> k));
+        TRY(dev_alloc(h, &h->PP, std::min<int64_t>(B, PP_IMG) * per, false));
+    }
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
     TRY(dev_alloc(h, &h->dout4, 2 * B * h->npi / 3 * 4));
     int64_t maxc = std::max<int64_t>(h->D0, F);
@@ -718,22 +726,32 @@ void forward(ctx_handle* h, int B, Mode mode) {
     const Scope st = scope_of(h, "conv"), cx = scope_of(h, "conv_context");
     float* src_z = h->Z + 2ll * B * F;
     const bool lanes = use_lanes(h) && mode != MODE_ENCODE;
+    // images through `conv_context`: B, or the ONE frame every row shares (its code and skip activations are then read with row stride 0
+    // / image index n % 1 by their consumers -- same values as B copies, 1 / B of the work)
+    const int nc = mode == MODE_TRANSLATE && h->ctx_single ? 1 : B;
     // refresh the 4-channel copy of the frames in use (what the cin = 3 loaders read)
     if (use_dc3(h)) {}
     else if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
     else pack_c4(h, h->img + B * npi, (mode == MODE_ENCODE ? 1ll : 2ll) * B * h->H * h->W);
+    // (a captured forward is SUBMITTED node by node in issue order, ~6.5 us per node: the reward hook's translate issues the longer
+    // `conv` chain first, so that it does not start behind the 12 nodes of the one-frame context chain)
+    const bool ctx_behind = lanes && mode == MODE_TRANSLATE;
+    auto ctx_lane = [&] {
+        LaneSwap sw(h, LANE_CTX);
+        encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0);
+    };
     if (lanes) {
         fork(h, LANE_CTX);
-        LaneSwap sw(h, LANE_CTX);
-        encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+        if (!ctx_behind) ctx_lane();
     }
     if (mode == MODE_TRAIN) encoder_fwd(h, "conv", st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
     else encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
     if (mode == MODE_ENCODE) return;
+    if (ctx_behind) ctx_lane();
     if (lanes) join(h, LANE_CTX);
-    else encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, B, h->c, h->cz, 0);
+    else encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0);
     // translate (arm_shaping.py:1309-1312): trans_h0 on concat([src_z, ctx_z], 1), then trans_z
-    KmPlain tcat{src_z, F, h->cz, F, F, B, 2 * F / KC, g_zeros};
+    KmPlain tcat{src_z, F, h->cz, nc == 1 && B > 1 ? 0 : F, F, B, 2 * F / KC, g_zeros};
     fc_layer(h, "translate/trans_h0", tcat, B, 2 * F, h->Wp("translate/trans_h0/Matrix"), h->Wp("translate/trans_h0/bias"), F, 1, h->th0);
     fc_layer(h, "translate/trans_z", km(h->th0, F, B, F), B, F, h->Wp("translate/trans_z/Matrix"), h->Wp("translate/trans_z/bias"), F, 0, h->Z);
     // decoder (arm_shaping.py:1321-1330, :1334-1343)
@@ -752,23 +770,31 @@ void forward(ctx_handle* h, int B, Mode mode) {
         if (k < 4) {
             const int R = nd * hs * ws;
             const bool wide = h->cfg.precision == CTX_PREC_F32 && wconvt_ok(hs, ws, c1, c2, ca, nd);
-            ProfScope ps(h, nm_ + " fwd", wide ? K_WCONVT : K_CONVT, fl, uf);
+            // starved inference launches (the reward hook's 25 frames): one plain product + a gather (launch.h: convt_product)
+            // (measured at 25 frames: 4x4 grid 130 -> 87 us; the 8x8 / 16x16 grids 75 / 73 -> 87 / 85 us, so those stay on the tiles)
+            const bool prod = mode != MODE_TRAIN && nd <= PP_IMG && hs * ws <= 16 && h->PP && (h->opt.v[OPT_WCONVT] & 16) && ca % 4 == 0 && (c1 + c2) % KC == 0 && c1 % KC == 0;
+            ProfScope ps(h, nm_ + " fwd", prod ? K_CONVT3P : wide ? K_WCONVT : K_CONVT, fl, uf);
             Epi ep;
             ep.out1 = h->e[k]; ep.ld1 = ca; ep.bias = b; ep.lrelu = 1;
-            if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, B, nd, hs, ws, w, ca, ep, ws_of(h));
-            else if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, B, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
+            if (prod) {
+                convt_product(h->stream, KmCat2{dec, c1, c1, skip, c2, nc, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, ca, h->PP, R, ws_of(h));
+                convt_gather(h->stream, h->PP, b, h->e[k], nd, hs, ws, ca, 1);
+            } else if (wide) wconvt_fwd(h->stream, dec, c1, skip, c2, nc, nd, hs, ws, w, ca, ep, ws_of(h));
+            else if (use_q(nd) && hs * ws >= q_minpos(h)) convt_fwd_q(h->stream, KmConvTGatherQ{dec, c1, c1, skip, c2, nc, make_tposgeo(hs, ws, 5, 1, (c1 + c2) / KC), nd, g_zeros},
                                        KmConvTWeightsQ{w, ca, c1 + c2, 5, g_zeros}, ep, ca, ws_of(h));
-            else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, B, hs, ws, (c1 + c2) / KC, R, g_zeros},
+            else convt_fwd(h->stream, KmConvTGather{dec, c1, c1, skip, c2, nc, hs, ws, (c1 + c2) / KC, R, g_zeros},
                            KmConvTWeights{w, ca, c1 + c2, (c1 + c2) / KC, g_zeros}, ep, R, ca, ws_of(h));
             dec = h->e[k];
         } else {
             const int R = nd * hs * ws;
-            if (d_h4_direct(h, c1, c2, hs, ws, 2)) {
+            // (the same for d_h4 at <= PP_IMG images: the direct kernel offers 200 two-wave tiles to 256 CUs there, 54 us at 25 frames)
+            const bool prod3 = mode != MODE_TRAIN && nd <= PP_IMG && (h->opt.v[OPT_WCONVT] & 16) && (c1 + c2) % KC == 0 && c1 % KC == 0;
+            if (d_h4_direct(h, c1, c2, hs, ws, 2) && !prod3) {
                 ProfScope ps(h, nm_ + " fwd", K_CONVT3D, fl, uf);
-                convt3_direct(h->stream, dec, c1, skip, c2, B, nd, hs, ws, 2, w, b, h->out);
+                convt3_direct(h->stream, dec, c1, skip, c2, nc, nd, hs, ws, 2, w, b, h->out);
             } else {
                 { ProfScope ps(h, nm_ + " fwd product", K_CONVT3P, fl, uf);
-                  convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, B, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
+                  convt3_product(h->stream, KmCat2{dec, c1, c1, skip, c2, nc, hs * ws, R, (c1 + c2) / KC, g_zeros}, w, c1 + c2, h->P3, R, ws_of(h)); }
                 { ProfScope ps(h, nm_ + " fwd gather", K_CONVT3, 0.0);
                   convt3_gather(h->stream, h->P3, b, h->out, nd, hs, ws); }
             }
@@ -969,7 +995,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
 // read through the arena pointer at replay.  CTX_GRAPHS=0 keeps plain launches.
 int forward_inference(ctx_handle* h, int B, Mode mode) {
     if (!h->use_graphs || h->prof_on || B > 64) { forward(h, B, mode); return CTX_OK; }
-    ctx_handle::GraphSlot& g = h->graphs[(int)mode * (1 << 20) + B];
+    ctx_handle::GraphSlot& g = h->graphs[(int)mode * (1 << 20) + (mode == MODE_TRANSLATE && h->ctx_single ? 1 << 19 : 0) + B];
     if (g.calls++ == 0) { forward(h, B, mode); return CTX_OK; }      // first call: plain (code objects, LDS limits)
     if (!g.exec) {
         hipGraph_t graph = nullptr;
@@ -1362,6 +1388,9 @@ int ctx_init_params(ctx_handle* h, uint64_t seed) {
     return finish(h);
 }
 
+// does this call run `conv_context` on one frame?  (the table-driven engine runs its whole graph on B rows)
+static bool single_ctx(const ctx_handle* h, int ctx_batched) { return !ctx_batched && !h->gen; }
+
 static int translate_tail(ctx_handle* h, int B, float* pred, float* feat) {
     TRY(forward_inference(h, B, MODE_TRANSLATE));
     if (pred) TRY(copy_d2h(h, pred, h->out, (size_t)B * h->npi * sizeof(float)));
@@ -1378,7 +1407,9 @@ int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ct
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;
     HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, src, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    for (int slot = 0; slot <= 2; slot += 2) {             // image[1] = image[2] = [context]*B (base.py:217-218)
+    h->ctx_single = single_ctx(h, ctx_batched);
+    if (h->ctx_single) HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, ctx0, (size_t)npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    else for (int slot = 0; slot <= 2; slot += 2) {        // image[1] = image[2] = [context]*B (base.py:217-218)
         float* dst = h->img + (int64_t)slot * B * npi;
         if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, ctx0, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
         else
@@ -1395,7 +1426,9 @@ int ctx_translate_dev(ctx_handle* h, const float* d_src, const float* d_ctx0, in
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;
     HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, d_src, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    for (int slot = 0; slot <= 2; slot += 2) {             // image[1] = image[2] = [context]*B (base.py:217-218)
+    h->ctx_single = single_ctx(h, ctx_batched);
+    if (h->ctx_single) HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, d_ctx0, (size_t)npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    else for (int slot = 0; slot <= 2; slot += 2) {        // image[1] = image[2] = [context]*B (base.py:217-218)
         float* dst = h->img + (int64_t)slot * B * npi;
         if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, d_ctx0, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         else
@@ -1446,7 +1479,9 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
     HIP_TRY(h, hipMemcpyAsync(u_src, src, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(u_ctx, ctx0, (size_t)(ctx_batched ? B : 1) * npi, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
+    h->ctx_single = single_ctx(h, ctx_batched);
     if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, B * npi);
+    else if (h->ctx_single) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi);        // the one frame `conv_context` reads
     else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi, B);
     if (h->gen) {   // the table-driven engine runs the whole graph: image[2] = [context]*B there (base.py:217-218)
         if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img, B * npi);

@@ -8,6 +8,13 @@ void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, floa
     ep.out1 = P; ep.ld1 = P3_LD;
     launch_igemm<KmCat2, KmPlain, false, 1, 2>(s, a, b, ep, M, 75, 1, 0, ws);
 }
+// the same product for a transposed conv to `ca` output channels: P[pixel][(ky*5+kx)*ca + c] (convt_gather adds the taps of an output pixel)
+void convt_product(hipStream_t s, const KmCat2& a, const float* w, int cb, int ca, float* P, int M, SplitWs ws) {
+    KmPlain b{w, cb, nullptr, 0, cb, 25 * ca, cb / KC, a.zeros};
+    Epi ep;
+    ep.out1 = P; ep.ld1 = 25 * ca;
+    launch_igemm<KmCat2, KmPlain, false, 1, 2>(s, a, b, ep, M, 25 * ca, 1, cb / KC, ws);
+}
 void convt3_product_t(hipStream_t s, const KmCat2& b, const float* w, int cb, float* PT, int M, SplitWs ws) {
     // rows = the 75 filter rows (tap, c), columns = pixels: D[t][pixel] = sum_k w[t][k] * cat[pixel][k]
     KmPlain a{w, cb, nullptr, 0, cb, 75, cb / KC, b.zeros};

@@ -47,7 +47,7 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
 namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[OPT_COUNT] = {
-    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 15}, {"direct3", 15}, {"dconv", 3},
+    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 31}, {"direct3", 15}, {"dconv", 3},
     {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"adam_prio", 2},
 };
 }  // namespace
@@ -262,6 +262,41 @@ __global__ __launch_bounds__(NTHREADS) void convt3_gather_kernel(const float* __
         float* o = out + idx * 3;
         o[0] = a0 + b0; o[1] = a1 + b1; o[2] = a2 + b2;
     }
+}
+
+// The same gather for `ca` output channels (ca % 4 == 0; convt_product's P, row stride 25 ca): one thread per output pixel and four channels.
+__global__ __launch_bounds__(NTHREADS) void convt_gather_kernel(const float* __restrict__ P, const float* __restrict__ bias, float* __restrict__ out,
+                                                                int nimg, int hs, int ws, int ca, int lrelu) {
+    const int wb = 2 * ws, hb = 2 * hs, c4n = ca >> 2;
+    const int64_t total = (int64_t)nimg * hb * wb * c4n;
+    for (int64_t idx = (int64_t)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NTHREADS) {
+        const int c = (int)(idx % c4n) * 4;
+        int64_t t = idx / c4n;
+        const int x = (int)(t % wb);
+        t /= wb;
+        const int y = (int)(t % hb), n = (int)(t / hb);
+        const int py = y & 1, px = x & 1, ip = y >> 1, jp = x >> 1;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sy = 0; sy < 2 + py; ++sy) {
+            const int i = ip + py - sy, ky = 1 - py + 2 * sy;
+            if ((unsigned)i >= (unsigned)hs) continue;
+            for (int sx = 0; sx < 2 + px; ++sx) {
+                const int j = jp + px - sx, kx = 1 - px + 2 * sx;
+                if ((unsigned)j >= (unsigned)ws) continue;
+                const float4 r = *reinterpret_cast<const float4*>(P + (((int64_t)n * hs + i) * ws + j) * (25 * ca) + (ky * 5 + kx) * ca + c);
+                a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w;
+            }
+        }
+        const float4 b = *reinterpret_cast<const float4*>(bias + c);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        if (lrelu) { a.x = fmaxf(a.x, LEAK * a.x); a.y = fmaxf(a.y, LEAK * a.y); a.z = fmaxf(a.z, LEAK * a.z); a.w = fmaxf(a.w, LEAK * a.w); }
+        *reinterpret_cast<float4*>(out + ((((int64_t)n * hb + y) * wb + x) * ca + c)) = a;
+    }
+}
+void convt_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws, int ca, int lrelu) {
+    int64_t blocks = ((int64_t)nimg * 4 * hs * ws * (ca / 4) + NTHREADS - 1) / NTHREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(convt_gather_kernel, dim3((unsigned)blocks), dim3(NTHREADS), 0, s, P, bias, out, nimg, hs, ws, ca, lrelu);
 }
 
 // The stride-1 form (ContextAEReal's d_h4) gathers from a TAP-MAJOR product PT[(tap*3+c)][pixel] (convt3_product_t): for a

@@ -120,7 +120,13 @@ bool convt3_direct_ok(int c1, int c2, int hin, int win, int stride);
 void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int c2, int nmod2, int nimg, int hin, int win, int stride,
                    const float* w, const float* bias, float* out);
 constexpr int P3_LD = 80;                   // row stride of P (75 used)
+constexpr int PP_IMG = 32;                  // most images of a launch that takes the product + gather route of convt_product
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);
+// conv2d_transpose 5x5 s2 as ONE plain product + a gather, for STARVED inference launches (the reward hook's 25 frames: a handful of
+// images cannot fill 256 CUs with image-major tiles, a [pixels x cb] x [cb x 25 ca] product can): P[pixel][(ky*5+kx)*ca + c], then
+// out[n, y, x, c] = act(b[c] + the 4-9 taps of (y, x)) in a fixed order.  All 25 taps of every input pixel are formed.
+void convt_product(hipStream_t s, const KmCat2& a, const float* w, int cb, int ca, float* P, int M, SplitWs ws);
+void convt_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws, int ca, int lrelu);
 void convt3_gather(hipStream_t s, const float* P, const float* bias, float* out, int nimg, int hs, int ws);
 // stride-1 variant: out[n,y,x,c] = b[c] + sum_{ky,kx} P[(n, y+2-ky, x+2-kx)][(ky*5+kx)*3+c]
 // tap-major variant: PT[(tap*3+c)][M pixels] = w (75 x cb) times the concat input, then a coalesced gather

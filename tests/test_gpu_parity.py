@@ -154,6 +154,9 @@ def test_adam_trajectory_matches_oracle(T, steps):
             r, _ = o.train_step(q, m, v, t, *(x.astype(np.float64) for x in (src, ctx, tgt)), 1e-3, cfg)
             sc = tr.train_step(src, ctx, tgt, lr=1e-3)
             assert abs(sc["loss"] - r["loss"]) <= 2e-5 * abs(r["loss"]), t
+            if t == 1:      # the moments of the FIRST step are the first gradient scaled: tight
+                m1, v1, _ = tr.get_adam_state()
+                assert rel_l2(m1, o.flatten(m, cfg)) < 1e-4 and rel_l2(v1, o.flatten(v, cfg)) < 1e-4
         got = tr.get_params()
         p0 = o.flatten(p, cfg)
         delta_ref = o.flatten(q, cfg) - p0
@@ -174,7 +177,11 @@ def test_adam_trajectory_matches_oracle(T, steps):
         assert rel_l2(delta_got, delta_ref) < 5e-3
         mm, vv, step = tr.get_adam_state()
         assert step == steps
-        assert rel_l2(mm, o.flatten(m, cfg)) < 1e-4 and rel_l2(vv, o.flatten(v, cfg)) < 1e-4
+        # (after three steps the moments carry the gradients of steps 2 and 3, i.e. of the slightly different models: the same 2-3e-3
+        # as the update -- tools/dbg_adam_traj.py prints it per tensor and step: <= 5e-5 after step 1, 3e-4 after step 2 in the tensors
+        # behind a flipped branch, 2-5e-3 after step 3)
+        em, ev = rel_l2(mm, o.flatten(m, cfg)), rel_l2(vv, o.flatten(v, cfg))
+        assert em < 5e-3 and ev < 1e-3, (em, ev)
 
 
 def test_inference_call_sites_match_oracle(T):
@@ -187,7 +194,10 @@ def test_inference_call_sites_match_oracle(T):
         opred, ofeat = o.translate(p, fr[0], fr[1][0], cfg)
         assert relmax(pred, opred) < 1e-4 and relmax(feat, ofeat) < 1e-4
         predb, featb = tr.translate(fr[0], np.broadcast_to(fr[1][0], fr[0].shape))
-        np.testing.assert_array_equal(pred, predb)           # [context]*B == broadcast
+        # [context]*B == one context frame: the single frame goes through `conv_context` ONCE (its code and skip activations are read by
+        # every row), the B copies through a batch-B launch whose split-K sums run in another order -- same values to f32 rounding
+        np.testing.assert_allclose(predb, pred, rtol=0, atol=1e-5 * np.abs(pred).max())
+        np.testing.assert_allclose(featb, feat, rtol=0, atol=1e-5 * np.abs(feat).max())
         f, x = tr.encode(fr[2])
         of, ox = o.encode(p, fr[2], cfg)
         np.testing.assert_array_equal(x, ox)                 # preprocessing is bit-exact: three rounded f32 ops
