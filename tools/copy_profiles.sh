@@ -9,7 +9,7 @@ cp $O/rp/r1_kernel_stats.csv ${P}_kernel_stats.csv
 cp $O/rp_lanes/r1_kernel_stats.csv ${P}_kernel_stats_lanes.csv
 cp $O/hbm_traffic.json ${P}_hbm_traffic.json
 cp $O/bench_force_dist.json ${P}_bench_force_dist_one_rank_rccl.json
-cp $O/reward.txt ${P}_reward_calls.txt
+cat $O/reward_latency.txt $O/reward.txt > ${P}_reward_calls.txt
 cp $O/real.txt ${P}_context_ae_real.txt
 cp $O/real_layers.txt ${P}_context_ae_real_layers.txt
 cp $O/config4.txt ${P}_config4_inception_end_to_end.txt

@@ -12,6 +12,7 @@ python bench.py --steps 30 --warmup 5 > $O/bench.json 2> $O/bench.err
 BENCH_LAYER_TABLE=$O/layer_table.txt python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --no-sampled --sustained-s 0 > /dev/null 2>&1
 BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split-leg --no-secondary --no-sampled --sustained-s 0 > $O/bench_force_dist.json 2> /dev/null
 python tools/bench_reward.py > $O/reward.txt 2>&1
+python tools/reward_latency.py 300 > $O/reward_latency.txt 2>&1
 python tools/bench_real.py > $O/real.txt 2>&1
 python tools/real_layer_table.py > $O/real_layers.txt 2>&1
 python tools/bench_config4.py 125 64 > $O/config4.txt 2>&1
