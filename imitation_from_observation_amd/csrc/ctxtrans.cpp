@@ -693,18 +693,19 @@ Scope scope_of(ctx_handle* h, const std::string& sc) {
 }
 
 // arm_shaping.py:1282-1288 / :1290-1307: four conv+lrelu, h4_lin+lrelu, hz_lin (+lrelu for `conv`)
-// layer k of the six (0-3: the convs, 4: h4_lin, 5: hz_lin)
-void encoder_layer(ctx_handle* h, const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* z,
-                   int z_lrelu, int k) {
-    const int d = h->d, F = h->F;
-    const int K3 = h->hh[4] * h->ww[4] * 8 * d;   // NHWC flatten, arm_shaping.py:1287
-    if (k < 4) conv_layer(h, scn + "/h" + std::to_string(k) + "_conv", k ? act[k - 1] : x, nimg, h->hh[k], h->ww[k], k ? d << (k - 1) : 3, sc.w[k], sc.b[k], act[k], d << k);
-    else if (k == 4) fc_layer(h, scn + "/h4_lin", km(act[3], K3, nimg, K3), nimg, K3, sc.w4, sc.b4, F, 1, act[4]);
-    else fc_layer(h, scn + "/hz_lin", km(act[4], F, nimg, F), nimg, F, sc.wz, sc.bz, F, z_lrelu, z);
-}
 void encoder_fwd(ctx_handle* h, const std::string& scn, const Scope& sc, const float* x, int nimg, float* const act[5], float* z,
                  int z_lrelu) {
-    for (int k = 0; k < 6; ++k) encoder_layer(h, scn, sc, x, nimg, act, z, z_lrelu, k);
+    const int d = h->d, F = h->F;
+    const float* in = x;
+    int ca = 3;
+    for (int k = 0; k < 4; ++k) {
+        conv_layer(h, scn + "/h" + std::to_string(k) + "_conv", in, nimg, h->hh[k], h->ww[k], ca, sc.w[k], sc.b[k], act[k], d << k);
+        in = act[k];
+        ca = d << k;
+    }
+    const int K3 = h->hh[4] * h->ww[4] * 8 * d;   // NHWC flatten, arm_shaping.py:1287
+    fc_layer(h, scn + "/h4_lin", km(act[3], K3, nimg, K3), nimg, K3, sc.w4, sc.b4, F, 1, act[4]);
+    fc_layer(h, scn + "/hz_lin", km(act[4], F, nimg, F), nimg, F, sc.wz, sc.bz, F, z_lrelu, z);
 }
 
 enum Mode { MODE_TRAIN, MODE_TRANSLATE, MODE_ENCODE };
@@ -732,24 +733,15 @@ void forward(ctx_handle* h, int B, Mode mode) {
     if (use_dc3(h)) {}
     else if (mode == MODE_TRAIN) pack_c4(h, h->img, 3ll * B * h->H * h->W);
     else pack_c4(h, h->img + B * npi, (mode == MODE_ENCODE ? 1ll : 2ll) * B * h->H * h->W);
-    // (a captured forward is SUBMITTED node by node in issue order, ~6.5 us per node, so whichever chain is issued second starts behind
-    // the 12 nodes of the first: the reward hook's translate issues the two chains layer by layer)
-    const bool zip = lanes && mode == MODE_TRANSLATE;
+    // (inside a captured translate the second branch starts ~70 us behind the first whichever chain is issued first, or layer by layer --
+    // measured, profiles/round5_c_reward_latency.txt; with ONE context frame its chain still ends before the 25-frame `conv` chain needs it)
     if (lanes) {
         fork(h, LANE_CTX);
-        if (!zip) {
-            LaneSwap sw(h, LANE_CTX);
-            encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0);
-        }
+        LaneSwap sw(h, LANE_CTX);
+        encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0);
     }
     if (mode == MODE_TRAIN) encoder_fwd(h, "conv", st, h->img, 2 * B, h->s, h->Z + (int64_t)B * F, 1);
-    else if (!zip) encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
-    else
-        for (int k = 0; k < 6; ++k) {
-            encoder_layer(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1, k);
-            LaneSwap sw(h, LANE_CTX);
-            encoder_layer(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0, k);
-        }
+    else encoder_fwd(h, "conv", st, h->img + B * npi, B, h->s, src_z, 1);
     if (mode == MODE_ENCODE) return;
     if (lanes) join(h, LANE_CTX);
     else encoder_fwd(h, "conv_context", cx, h->img + 2 * B * npi, nc, h->c, h->cz, 0);
