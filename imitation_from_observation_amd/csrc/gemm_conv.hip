@@ -25,7 +25,8 @@ void conv_fwd_q(hipStream_t s, const KmConvGatherQ& a, const NmConvWeightsQ& b, 
     std::vector<int> wt((size_t)g.hs * g.ws);
     for (int i = 0; i < g.hs; ++i)
         for (int j = 0; j < g.ws; ++j) wt[(size_t)i * g.ws + j] = nt(g.s * i, g.hb, g.pad, g.K) * nt(g.s * j, g.wb, g.px(), g.kw());
-    const bool bal = (balance_bits() & 2) || ((balance_bits() & 1) && g.hs * g.ws <= 16);
+    const bool bal = ((balance_bits() & 2) && !(balance_bits() & 8)) || ((balance_bits() & 1) && g.hs * g.ws <= 16);
+    if ((balance_bits() & 8) && g.hs * g.ws > 16) ep.perm = morton_order(g.hs, g.ws, s);
     launch_igemm<KmConvGatherQ, NmConvWeightsQ, true, 1, 0>(s, a, b, ep, a.nimg, N, a.g.hs * a.g.ws, posgeo_min_chunks(a.g), ws, 0, bal ? wt.data() : nullptr);
 }
 }  // namespace ctx

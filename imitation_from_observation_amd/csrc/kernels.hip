@@ -47,7 +47,7 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
 namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[OPT_COUNT] = {
-    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 3}, {"wconvt", 31}, {"direct3", 15}, {"dconv", 3},
+    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 9}, {"wconvt", 31}, {"direct3", 15}, {"dconv", 3},
     {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"adam_prio", 2},
 };
 }  // namespace
@@ -131,6 +131,40 @@ const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tile
     if (hipMemcpy(dptr, order.data(), nprob * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dptr); return nullptr; }
     cache[{dev, key}] = dptr;
     return dptr;
+}
+
+// a fixed problem order as a cached DEVICE array (same lifetime rules as balanced_order's)
+const uint16_t* device_order(const std::vector<uint16_t>& order, hipStream_t stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, std::vector<uint16_t>>, uint16_t*> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find({dev, order});
+    if (it != cache.end()) return it->second;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return nullptr;
+    uint16_t* dptr = nullptr;
+    if (hipMalloc((void**)&dptr, order.size() * sizeof(uint16_t)) != hipSuccess) return nullptr;
+    if (hipMemcpy(dptr, order.data(), order.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dptr); return nullptr; }
+    cache[{dev, order}] = dptr;
+    return dptr;
+}
+// Z-order (Morton) walk of a gh x gw grid, column bit lowest: any contiguous range of the walk is a 2-D compact patch, so the run an
+// XCD is given (and the 8-16 problems of it that are resident together) re-reads few input pixels from outside its own L2.
+const uint16_t* morton_order(int gh, int gw, hipStream_t stream) {
+    if (gh * gw > 65535) return nullptr;
+    std::vector<std::pair<uint32_t, uint16_t>> key;
+    for (int i = 0; i < gh; ++i)
+        for (int j = 0; j < gw; ++j) {
+            uint32_t k = 0;
+            for (int b = 0; b < 12; ++b) k |= ((uint32_t)(j >> b) & 1u) << (2 * b) | ((uint32_t)(i >> b) & 1u) << (2 * b + 1);
+            key.push_back({k, (uint16_t)(i * gw + j)});
+        }
+    std::sort(key.begin(), key.end());
+    std::vector<uint16_t> order;
+    for (auto& kv : key) order.push_back(kv.second);
+    return device_order(order, stream);
 }
 
 namespace { thread_local char g_launch_err[256]; thread_local bool g_launch_err_set = false; }

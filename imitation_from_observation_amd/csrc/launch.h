@@ -32,11 +32,15 @@ void ensure_dyn_lds(const void* kernel, size_t bytes);
 // allocate or copy synchronously -- that would invalidate the capture: it returns nullptr (the kernel's plain order) and the next
 // un-captured launch of that shape creates the entry.
 const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem, hipStream_t stream);
+const uint16_t* morton_order(int gh, int gw, hipStream_t stream);      // Z-order walk of a grid of problems (kernels.hip)
 // CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (the 4x4
 // layers: d_h1's input gradient 0.675 -> 0.59 ms, h3_conv forward 0.352 -> 0.316); 2 = on larger grids too (with the pair-aware order
 // inside a run: -0.03 ms of step; before it the scattered positions of an 8x8 grid cost more L2 misses than the 7.5 % imbalance);
-// 4 = the rectangle-ordered filter gradient's 25 taps (+0.05 ms of step: its launches run several rounds and balance themselves).
-// Default 3.
+// 4 = the rectangle-ordered filter gradient's 25 taps (+0.05 ms of step: its launches run several rounds and balance themselves);
+// 8 (round 5) = larger grids in Z-order instead of 2: an XCD's run, and the 8-16 problems of it that are resident together, is a 2-D
+// compact patch of positions -- 560 -> 431 MB of HBM traffic per launch (row-major runs: 462) at the same step time as the balanced
+// order (13.69 / 13.68 against 13.70 / 13.81 ms on one box; row-major 13.91), profiles/round5_d_conv_gather_order.txt.
+// Default 9.
 int balance_bits();
 
 // Split-K policy shared by all launchers: `slab` is scratch of `slab_floats` floats.

@@ -13,7 +13,8 @@ enum Opt {
     OPT_GRAPH_LANES,   // 1: the captured inference forward keeps the stream lanes as graph branches (translate: both encoders side by side)
     OPT_POSMAJOR,      // 1: position-major convolutions (only the taps inside the grid) at >= 64 images
     OPT_XCD_SWIZZLE,   // bits: 1 position-major conv, 2 position-major transposed conv, 4 rectangle-ordered filter gradient: contiguous runs of work per XCD
-    OPT_BALANCE,       // bits: 1 load-balanced problem order on <= 16-position grids, 2 on larger grids, 4 for the filter gradient's taps
+    OPT_BALANCE,       // bits: position-major conv: 1 load-balanced problem order on <= 16-position grids, 2 on larger grids, 8 Z-order runs on larger
+                       // grids instead (wins over 2); 4 load-balanced taps in the filter gradient
     OPT_WCONVT,        // bits: 1 LDS-resident transposed conv (wconvt.hip), 2 row blocks on 4x4 grids, 4 row blocks on 8x8 grids, 8 column-uniform waves,
                        // 16 inference launches of <= 32 images as one product + a gather (launch.h: convt_product)
     OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3)

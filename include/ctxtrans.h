@@ -123,7 +123,8 @@ const char* ctx_last_error(const ctx_handle* h);
  *   graph_lanes  1   ... with the stream lanes captured as graph branches (translate: the two encoders run side by side)
  *   posmajor     1   position-major convolutions (only the taps inside the grid) from 64 images up
  *   xcd_swizzle  7   bits: contiguous runs of work per XCD for 1 the position-major conv, 2 the transposed conv, 4 the filter gradient
- *   balance      3   bits: load-balanced problem order 1 on grids of <= 16 positions, 2 on larger grids, 4 for the filter gradient's taps
+ *   balance      9   bits: problem order of the position-major conv: 1 load-balanced runs on grids of <= 16 positions, 2 on larger grids,
+ *                    8 Z-order (2-D compact) runs on larger grids instead (wins over 2); 4 load-balanced taps in the filter gradient
  *   wconvt      31   bits: 1 LDS-resident transposed conv, 2 / 4 row blocks on 4x4 / 8x8 grids, 8 column-uniform waves (4x4),
  *                    16 inference launches of <= 32 images as one product + a gather
  *   direct3     15   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass  [fixed at create]
