@@ -1383,8 +1383,8 @@ int ctx_init_params(ctx_handle* h, uint64_t seed) {
     return finish(h);
 }
 
-// does this call run `conv_context` on one frame?  (the table-driven engine runs its whole graph on B rows)
-static bool single_ctx(const ctx_handle* h, int ctx_batched) { return !ctx_batched && !h->gen; }
+// ContextAEInception2's `out = decode + tgtctx` (arm_shaping.py:1890-1891)
+static bool residual_out(const ctx_handle* h) { return h->gen && h->gen->residual; }
 
 static int translate_tail(ctx_handle* h, int B, float* pred, float* feat) {
     TRY(forward_inference(h, B, MODE_TRANSLATE));
@@ -1402,15 +1402,11 @@ int ctx_translate_f32(ctx_handle* h, const float* src, const float* ctx0, int ct
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;
     HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, src, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    h->ctx_single = single_ctx(h, ctx_batched);
-    if (h->ctx_single) HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, ctx0, (size_t)npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    else for (int slot = 0; slot <= 2; slot += 2) {        // image[1] = image[2] = [context]*B (base.py:217-218)
-        float* dst = h->img + (int64_t)slot * B * npi;
-        if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, ctx0, (size_t)B * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
-        else
-            for (int b = 0; b < B; ++b)
-                HIP_TRY(h, hipMemcpyAsync(dst + (int64_t)b * npi, ctx0, (size_t)npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    }
+    // one context frame: encoded once, read by every row (forward); B frames: one per row.  (translate reads nothing of the tgt slot)
+    h->ctx_single = !ctx_batched;
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, ctx0, (size_t)(ctx_batched ? B : 1) * npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (!ctx_batched && residual_out(h))           // out = decode + tgtctx reads the context frame of every row
+        for (int b = 1; b < B; ++b) HIP_TRY(h, hipMemcpyAsync(h->img + (2ll * B + b) * npi, ctx0, (size_t)npi * sizeof(float), hipMemcpyHostToDevice, h->stream));
     return translate_tail(h, B, pred, feat);
 }
 
@@ -1421,15 +1417,10 @@ int ctx_translate_dev(ctx_handle* h, const float* d_src, const float* d_ctx0, in
     HIP_TRY(h, hipSetDevice(h->device));
     const int64_t npi = h->npi;
     HIP_TRY(h, hipMemcpyAsync(h->img + B * npi, d_src, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    h->ctx_single = single_ctx(h, ctx_batched);
-    if (h->ctx_single) HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, d_ctx0, (size_t)npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    else for (int slot = 0; slot <= 2; slot += 2) {        // image[1] = image[2] = [context]*B (base.py:217-218)
-        float* dst = h->img + (int64_t)slot * B * npi;
-        if (ctx_batched) HIP_TRY(h, hipMemcpyAsync(dst, d_ctx0, (size_t)B * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-        else
-            for (int b = 0; b < B; ++b)
-                HIP_TRY(h, hipMemcpyAsync(dst + (int64_t)b * npi, d_ctx0, (size_t)npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-    }
+    h->ctx_single = !ctx_batched;
+    HIP_TRY(h, hipMemcpyAsync(h->img + 2ll * B * npi, d_ctx0, (size_t)(ctx_batched ? B : 1) * npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    if (!ctx_batched && residual_out(h))
+        for (int b = 1; b < B; ++b) HIP_TRY(h, hipMemcpyAsync(h->img + (2ll * B + b) * npi, d_ctx0, (size_t)npi * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
     return translate_tail(h, B, pred, feat);
 }
 
@@ -1474,14 +1465,8 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
     HIP_TRY(h, hipMemcpyAsync(u_src, src, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(u_ctx, ctx0, (size_t)(ctx_batched ? B : 1) * npi, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
-    h->ctx_single = single_ctx(h, ctx_batched);
-    if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, B * npi);
-    else if (h->ctx_single) u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi);        // the one frame `conv_context` reads
-    else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, npi, B);
-    if (h->gen) {   // the table-driven engine runs the whole graph: image[2] = [context]*B there (base.py:217-218)
-        if (ctx_batched) u8_to_f32(h->stream, u_ctx, h->img, B * npi);
-        else broadcast_rows_u8_to_f32(h->stream, u_ctx, h->img, npi, B);
-    }
+    h->ctx_single = !ctx_batched;                 // one context frame: encoded once, read by every row (forward)
+    u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, (ctx_batched ? B : 1) * npi);
     return translate_tail(h, B, pred, feat);
 }
 

@@ -477,11 +477,6 @@ void u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t n) {
     hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_blocks(n / 4)), dim3(NTHREADS), 0, s, in, out, n, n);
 }
 
-void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows) {
-    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_blocks(row_elems * nrows / 4)), dim3(NTHREADS), 0, s, in, out,
-                       row_elems * nrows, row_elems);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Batch sampler on device (scripts/train_script.py:153-159): from the resident uint8 demo tensor
 // vdata[T][N][H*W*3] build img = [tgt | src | ctx]:

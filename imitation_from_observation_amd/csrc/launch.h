@@ -145,8 +145,6 @@ void pad_channels_u8(hipStream_t s, const uint8_t* in, float* out, int64_t npix,
 void pad_channels_f32(hipStream_t s, const float* in, float* out, int64_t npix, int cpad);
 void maxpool3x3s2(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo);
 void avgpool3x3s1(hipStream_t s, const float* in, float* out, int nimg, int hi, int wi, int c, int ldo);
-// out[r] = in[r % nrows_in] -- the [context]*batch_size broadcast of base.py:217-218
-void broadcast_rows_u8_to_f32(hipStream_t s, const uint8_t* in, float* out, int64_t row_elems, int64_t nrows);
 
 // device batch sampler (scripts/train_script.py:153-159); lut[256] = f32(x / 127.5 - 1)
 void gather_triples(hipStream_t s, const uint8_t* vdata, int T, int N, int64_t npi, const int* csrc, const int* ctgt, int B, int b0,

@@ -365,7 +365,7 @@ __device__ __forceinline__ void wr_lane_pos(int wv, int row, int& il, int& pj) {
 template <int HS, int WS, int RT, int PB, bool XS = false>
 __device__ __forceinline__ void wr_body(const WcT& P, float* smem, int img0, int r, int n0, int rot = 0) {
     using G = WrGeo<WS, PB>;
-    constexpr int IMGT = G::IMGT, HP = G::HP, WPL = G::WPL, TPIX = G::TPIX, LEAD = G::LEAD, COLS = G::COLS;
+    constexpr int HP = G::HP, WPL = G::WPL, TPIX = G::TPIX, LEAD = G::LEAD, COLS = G::COLS;
     constexpr int NPA = (TPIX * 8 + WC_THREADS - 1) / WC_THREADS;
     constexpr int BSTAGE = COLS * WC_LDP, NPB = COLS * 8 / WC_THREADS;
     constexpr int NT = wr_count(RT);
