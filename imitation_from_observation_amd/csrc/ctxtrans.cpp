@@ -348,7 +348,10 @@ int dev_alloc(ctx_handle* h, T** p, int64_t count, bool whole_tensor = true) {
     // debugging aid: CTX_DEBUG_POISON=1 fills every fresh buffer with 0xFF bytes (float NaN) so that a kernel reading memory nothing has
     // written shows up as NaN on every run instead of as a rare mismatch that depends on what the allocator handed back
     static const bool poison = getenv("CTX_DEBUG_POISON") && atoi(getenv("CTX_DEBUG_POISON"));
-    if (poison) (void)hipMemset(q, 0xFF, (size_t)count * sizeof(T));
+    if (poison) {      // (the fill runs on the null stream, which the handle's non-blocking streams do not wait for: finish it here)
+        (void)hipMemset(q, 0xFF, (size_t)count * sizeof(T));
+        (void)hipDeviceSynchronize();
+    }
     return CTX_OK;
 }
 
