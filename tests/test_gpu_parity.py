@@ -198,6 +198,9 @@ def test_inference_call_sites_match_oracle(T):
         # every row), the B copies through a batch-B launch whose split-K sums run in another order -- same values to f32 rounding
         np.testing.assert_allclose(predb, pred, rtol=0, atol=1e-5 * np.abs(pred).max())
         np.testing.assert_allclose(featb, feat, rtol=0, atol=1e-5 * np.abs(feat).max())
+        predr, featr = tr.translate(fr[0], fr[1])             # a context frame per row
+        opredr, ofeatr = o.translate(p, fr[0], fr[1], cfg)
+        assert relmax(predr, opredr) < 1e-4 and relmax(featr, ofeatr) < 1e-4
         f, x = tr.encode(fr[2])
         of, ox = o.encode(p, fr[2], cfg)
         np.testing.assert_array_equal(x, ox)                 # preprocessing is bit-exact: three rounded f32 ops

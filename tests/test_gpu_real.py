@@ -78,6 +78,13 @@ def test_real_forward_backward_matches_oracle(T, H, W, B):
         c0 = np.broadcast_to(o.preprocess_u8(fr[1][0]), src.shape).astype(np.float64)
         tres, _ = r.forward(p, src.astype(np.float64), c0, c0, cfg)
         assert relmax(pred, tres["out"]) < 1e-5 and relmax(feat, tres["translated_z"]) < 1e-5
+        # one context frame (encoded once, shared by the rows) == the same frame handed over B times; a context frame PER ROW is its own case
+        predb, featb = tr.translate(fr[0], np.broadcast_to(fr[1][0], fr[0].shape))
+        np.testing.assert_allclose(predb, pred, rtol=0, atol=1e-5 * np.abs(pred).max())
+        np.testing.assert_allclose(featb, feat, rtol=0, atol=1e-5 * np.abs(feat).max())
+        predr, featr = tr.translate(fr[0], fr[1])
+        rres, _ = r.forward(p, src.astype(np.float64), ctx.astype(np.float64), ctx.astype(np.float64), cfg)
+        assert relmax(predr, rres["out"]) < 1e-5 and relmax(featr, rres["translated_z"]) < 1e-5
         f, x = tr.encode(fr[2])
         np.testing.assert_array_equal(x, tgt)
         assert relmax(f, r._encode(p, tgt.astype(np.float64))[5]) < 1e-5
