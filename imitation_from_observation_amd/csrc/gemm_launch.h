@@ -6,6 +6,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <type_traits>
 #include <typeinfo>
 
 #include "launch.h"
@@ -74,6 +75,8 @@ static void launch_128(hipStream_t s, const LA& a, const LB& b, const Epi& ep, i
     }
 }
 
+template <class L> struct is_plain_loader : std::integral_constant<bool, std::is_same<L, KmPlain>::value || std::is_same<L, NmPlain>::value || std::is_same<L, NmPlain2>::value> {};
+
 // prob_weight (optional, nprob entries): relative length of each problem -- the launcher then runs them in balanced_order
 template <class LA, class LB, bool BIG = false, int W32 = 1, int WSP = 0>
 static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M, int N, int nprob, int min_chunks,
@@ -90,7 +93,17 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     // (a 256x64 tile of four 64x64 waves for N <= 64 was measured: 1 block/CU, -15..-25 % vs 128x64; not kept)
     // 128-wide tiles unless they would be >= 20 % padding where 64-wide ones are not (192 images or 192 channels: 3 x 64, not 2 x 128)
     auto wide = [](int X) { if (X <= 64) return 1; const int w128 = (X + 127) / 128 * 128, w64 = (X + 63) / 64 * 64; return (w128 - w64) * 5 >= w128 ? 1 : 2; };
-    const int MI = wide(M), NI = wide(N);
+    int MI = wide(M), NI = wide(N);
+    // FC layers (one problem, plain operands) on 64x64 tiles: four times the tiles for a quarter of the split-K -- shorter slabs and
+    // combines, and blocks that fit beside the conv launches of the other lanes.  Whole-step A/B on one box, two runs each (round 5):
+    // all 128x128: 13.00 / 12.94 ms; launches of <= 64 tiles: 12.87 / 12.91; <= 128: 12.90 / 12.87; all: 12.85 / 12.83 -- with the FC filter
+    // gradients (NmPlain x NmPlain) slower in the last (0.313 -> 0.324 ms), so those switch only up to 128 tiles.  Exact f32 only.
+    if (nprob == 1 && !ws.prec && is_plain_loader<LA>::value && is_plain_loader<LB>::value && M >= 128 && N >= 128) {
+        static const int knob = getenv("CTX_FC_SMALL") ? atoi(getenv("CTX_FC_SMALL")) : -1;       // (experiments: 0 = off, t = threshold for every pair)
+        const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+        const bool dw = !LA::KM && !LB::KM;
+        if (knob < 0 ? (!dw || t128 <= 128) : t128 <= knob) MI = NI = 1;
+    }
     const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
     // Split-K by a cost model, not a block-count target: a launch takes `rounds` passes over the resident
     // slots (256 CUs x blocks/CU allowed by LDS), so 400 or 800 blocks on 512 slots run at 78 % -- the split
