@@ -98,6 +98,11 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     // combines, and blocks that fit beside the conv launches of the other lanes.  Whole-step A/B on one box, two runs each (round 5):
     // all 128x128: 13.00 / 12.94 ms; launches of <= 64 tiles: 12.87 / 12.91; <= 128: 12.90 / 12.87; all: 12.85 / 12.83 -- with the FC filter
     // gradients (NmPlain x NmPlain) slower in the last (0.313 -> 0.324 ms), so those switch only up to 128 tiles.  Exact f32 only.
+    // The other one-problem launches (image-major convs and the transposed-conv products of small-batch inference calls, the front end's
+    // small maps): 64x64 tiles up to 256 tiles' worth -- translate at 25 frames 0.63 -> 0.60 ms, encode 0.281 -> 0.272, config 4's step
+    // 6.445 -> 6.395 ms; without the cap the Inception front end loses 1 % (3.92 -> 3.96 ms).
+    if (nprob == 1 && !ws.prec && !(is_plain_loader<LA>::value && is_plain_loader<LB>::value) && M >= 128 && N >= 128 &&
+        (int64_t)((M + 127) / 128) * ((N + 127) / 128) <= 256) MI = NI = 1;
     if (nprob == 1 && !ws.prec && is_plain_loader<LA>::value && is_plain_loader<LB>::value && M >= 128 && N >= 128) {
         static const int knob = getenv("CTX_FC_SMALL") ? atoi(getenv("CTX_FC_SMALL")) : -1;       // (experiments: 0 = off, t = threshold for every pair)
         const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
