@@ -122,9 +122,14 @@ def secondary_legs(device, steps=40):
             d = [(torch.randint(0, 256, (Bb, Hh, Ww, 3), device="cuda", generator=g, dtype=torch.uint8).float() / 127.5 - 1.0).contiguous()
                  for _ in range(3)]
             torch.cuda.synchronize()
-            for _ in range(5):
-                tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
-            tr.sync()
+            # warm up by TIME, not by count: the handle's creation leaves the GPU idle long enough for the clock to fall back, and five
+            # 3 ms steps do not bring it up again (the same build read 2.6 and 3.0 ms on one box depending on what ran before)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.3:
+                for _ in range(5):
+                    tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
+                tr.sync()
+            steps = max(steps, 100)
             t0 = time.perf_counter()
             for _ in range(steps):
                 tr.dev_train_step(*(t.data_ptr() for t in d), Bb, 1e-4)
@@ -158,9 +163,11 @@ def secondary_legs(device, steps=40):
             dd = front.features_dev(frames.data_ptr(), 3 * Bc)
             tr.dev_train_step(dd, dd + Bc * per, dd + 2 * Bc * per, Bc, 1e-4)
 
-        for _ in range(3):
-            step()
-        tr.sync()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:                      # (warm-up by time, as above)
+            for _ in range(3):
+                step()
+            tr.sync()
         n = max(10, steps // 2)
         t0 = time.perf_counter()
         for _ in range(n):

@@ -499,7 +499,9 @@ void adam_begin(ctx_handle* h, float lr) {
     h->adam_t += 1;
     h->adam_lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t)));
     h->adam_done.clear();
-    h->adam_early_on = env_on && h->adam_stream && use_lanes(h);
+    // (only where the update is worth hiding: ContextAEReal's 1.2 M parameters are a 7 us update, and the slices' events and queue hops
+    // among its 5-30 us launches cost 0.4 ms of a 2.6 ms step -- tools/secondary_gap.py: 3.00 -> 2.58 ms, round 5)
+    h->adam_early_on = env_on && h->adam_stream && use_lanes(h) && h->P >= (4ll << 20);
 }
 // [first, end) is final in the order of the CURRENT stream plus (lane >= 0) of that side lane
 void adam_early(ctx_handle* h, int64_t first, int64_t end, int lane) {
