@@ -104,10 +104,9 @@ static void launch_igemm(hipStream_t s, const LA& a, const LB& b, Epi ep, int M,
     if (nprob == 1 && !ws.prec && !(is_plain_loader<LA>::value && is_plain_loader<LB>::value) && M >= 128 && N >= 128 &&
         (int64_t)((M + 127) / 128) * ((N + 127) / 128) <= 256) MI = NI = 1;
     if (nprob == 1 && !ws.prec && is_plain_loader<LA>::value && is_plain_loader<LB>::value && M >= 128 && N >= 128) {
-        static const int knob = getenv("CTX_FC_SMALL") ? atoi(getenv("CTX_FC_SMALL")) : -1;       // (experiments: 0 = off, t = threshold for every pair)
         const int64_t t128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
         const bool dw = !LA::KM && !LB::KM;
-        if (knob < 0 ? (!dw || t128 <= 128) : t128 <= knob) MI = NI = 1;
+        if (!dw || t128 <= 128) MI = NI = 1;
     }
     const int64_t tiles = (int64_t)((M + 64 * MI - 1) / (64 * MI)) * ((N + 64 * NI - 1) / (64 * NI)) * nprob;
     // Split-K by a cost model, not a block-count target: a launch takes `rounds` passes over the resident
