@@ -98,7 +98,8 @@ struct ctx_handle {
     float *wpack = nullptr, *wpackL[NLANE] = {};   // dconv's re-packed filters, one buffer per stream lane (concurrent launches)
     bool overlap = true;
     // hipGraph cache of the two inference forwards (reward hook: batch-25 calls are launch-bound): key = mode * 2^20 + B
-    struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; };
+    struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; uint64_t pack_version = 0; };
+    DcPackCache pack;                // packed filters of the direct kernels, valid for pack.version (dconv.h); bumped wherever parameters change
     bool ctx_single = false;         // MODE_TRANSLATE with ONE context frame for the whole batch (`[context] * batch_size`, base.py:217-218):
                                      // `conv_context` runs on that one frame and its outputs are read by every row (forward)
     std::map<int, GraphSlot> graphs;
@@ -499,6 +500,7 @@ void adam_begin(ctx_handle* h, float lr) {
     h->adam_t += 1;
     h->adam_lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow(b2, (double)h->adam_t)) / (1.0 - std::pow(b1, (double)h->adam_t)));
     h->adam_done.clear();
+    h->pack.version++;               // the parameters change in this step: packed filters are stale from here on
     // (only where the update is worth hiding: ContextAEReal's 1.2 M parameters are a 7 us update, and the slices' events and queue hops
     // among its 5-30 us launches cost 0.4 ms of a 2.6 ms step -- tools/secondary_gap.py: 3.00 -> 2.58 ms, round 5)
     h->adam_early_on = env_on && h->adam_stream && use_lanes(h) && h->P >= (4ll << 20);
@@ -636,7 +638,7 @@ void conv_layer(ctx_handle* h, const std::string& name, const float* x, int nimg
     if (c3) c3conv(h->stream, x, nimg, hb, wb, 2, w, cb, ep);
     else if (ca == 3 && use_dc3(h)) {
         DcFwd P{};
-        P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack;
+        P.x1 = x; P.ld1 = 3; P.c1 = 3; P.CI = 3; P.hin = hb; P.win = wb; P.nimg = nimg; P.w = w; P.wmode = 0; P.N = cb; P.ep = ep; P.wp = h->wpack; P.pc = &h->pack;
         dconv_conv(h->stream, P, 2, 1);
     } else if (ca == 3) conv3_fwd(h->stream, KmC3Gather{c4of(h, x), hb, wb, hs, ws, R, g_zeros}, NmC3Weights{w, cb, g_zeros}, ep, R, cb, ws_of(h));
     else if (use_q(nimg)) conv_fwd_q(h->stream, KmConvGatherQ{x, ca, make_posgeo(hs, ws, hb, wb, 2, 1, 5, ca / KC), nimg, g_zeros}, NmConvWeightsQ{w, ca, cb, 5, g_zeros}, ep, cb, ws_of(h));
@@ -852,7 +854,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
             } else {
               ProfScope ps(h, nm_ + " dx", K_DCFWD, fl, uf);
               DcFwd D{};
-              D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack;
+              D.x1 = dy; D.ld1 = 3; D.c1 = 3; D.CI = 3; D.hin = hb; D.win = wb; D.nimg = 2 * B; D.w = w; D.wmode = 0; D.N = cb; D.ep = ed; D.wp = h->wpack; D.pc = &h->pack;
               dconv_conv(h->stream, D, 2, 1); }
         } else if (ca == 3) {
             { Side sd(h, LANE_DW);
@@ -996,7 +998,12 @@ void backward(ctx_handle* h, int B, int sim_batch) {
 int forward_inference(ctx_handle* h, int B, Mode mode) {
     if (!h->use_graphs || h->prof_on || B > 64) { forward(h, B, mode); return CTX_OK; }
     ctx_handle::GraphSlot& g = h->graphs[(int)mode * (1 << 20) + (mode == MODE_TRANSLATE && h->ctx_single ? 1 << 19 : 0) + B];
-    if (g.calls++ == 0) { forward(h, B, mode); return CTX_OK; }      // first call: plain (code objects, LDS limits)
+    if (g.exec && g.pack_version != h->pack.version) {               // parameters changed since the capture: its launches skip the filter packs
+        (void)hipGraphExecDestroy(g.exec);                           // that a plain pass now has to redo (dconv.h: DcPackCache)
+        g.exec = nullptr;
+        g.calls = 0;
+    }
+    if (g.calls++ == 0) { forward(h, B, mode); return CTX_OK; }      // first call: plain (code objects, LDS limits, filter packs)
     if (!g.exec) {
         hipGraph_t graph = nullptr;
         h->capturing = true;                                         // (lanes inside the capture: option graph_lanes)
@@ -1007,6 +1014,7 @@ int forward_inference(ctx_handle* h, int B, Mode mode) {
         }
         h->capturing = false;
         if (e == hipSuccess && graph) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+        g.pack_version = h->pack.version;
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess || !g.exec) {                            // capture not possible here: stay on plain launches
             (void)hipGetLastError();
@@ -1232,6 +1240,12 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
         }
     }
     if (rc == CTX_OK) rc = h->gen ? gen_alloc(h) : alloc_buffers(h);
+    // packed-filter cache (dconv.h: DcPackCache): only where the library owns the parameters -- a caller-owned arena (ctx_create_ex) may be
+    // written behind the handle's back, there every launch packs as before
+    if (rc == CTX_OK && h->own_arena) {
+        h->pack.floats = 4ll << 20;
+        rc = dev_alloc(h, &h->pack.arena, h->pack.floats, false);
+    }
     if (rc == CTX_OK) {
         // -1 = by size: the lanes pay where the launches are long enough to hide a cross-queue hop (measured 11.5 us each; a step has ~25
         // of them).  On ContextAEInception2's 2x2 maps they gain 0.07 ms of 2.7 alone and LOSE 0.23 ms of 6.85 behind the front end on a
@@ -1316,6 +1330,7 @@ int ctx_param_info(const ctx_handle* h, int index, const char** name, int* ndim,
 
 static int arena_io(ctx_handle* h, int slot, float* host, const float* chost, size_t n) {
     if (!h) return CTX_E_INVALID;
+    if (chost && slot == 0) h->pack.version++;
     if ((int64_t)n != h->P) return fail(h, CTX_E_INVALID, "expected %lld floats, got %zu", (long long)h->P, n);
     HIP_TRY(h, hipSetDevice(h->device));
     float* dev = h->arena + slot * h->Ppad;
@@ -1792,6 +1807,7 @@ int ctx_dp_init(ctx_handle* h, const uint8_t id[CTX_DP_UNIQUE_ID_BYTES], int ran
     RCCL_TRY(h, rccl().GroupStart());
     for (int slot : {0, 2, 3}) {
         float* p = h->arena + (int64_t)slot * h->Ppad;
+        h->pack.version++;
         RCCL_TRY(h, rccl().Broadcast(p, p, (size_t)h->Ppad, ncclFloat, 0, h->dp_comm, h->dp_stream));
     }
     RCCL_TRY(h, rccl().GroupEnd());

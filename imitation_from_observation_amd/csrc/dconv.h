@@ -43,6 +43,8 @@ struct DcClass {
                                        // e / ntx = (e * mdiv) >> 8 for e < 25 -- pure ALU, no table read in the MFMA loop
 };
 
+struct DcPackCache;
+
 struct DcFwd {
     const float* x1; int ld1; int c1;              // input channels [0, c1)
     const float* x2; int ld2; int nmod2;           // input channels [c1, CI): tensor 2, image index img % nmod2 (the ctx skip)
@@ -65,7 +67,27 @@ struct DcFwd {
     int tiles_y, tiles_x;
     Epi ep;
     unsigned long long* trace = nullptr;           // -DDC_TRACE builds of tools/dconv_bench.hip: s_memtime stamps [block][wave][tile][8] (never set by the product)
+    DcPackCache* pc = nullptr;                     // host side only: where packed filters are kept between launches (null: pack into wp every time)
 };
+
+// Packed-filter cache of one handle.  The LDS image of a layer's filter (dconv_pack_kernel) depends on the parameters and on the layer's
+// shape only, so it is packed ONCE per parameter version into a slot of `arena` instead of by a tiny launch in front of every
+// convolution (four launches in a 0.18 ms ContextAEReal encode call; same-box A/B at 25 frames: encode 0.182 -> 0.175 ms, translate
+// 0.357 -> 0.342, 64x64 0.390 -> 0.373).  The owner
+// bumps `version` whenever a parameter may have changed (Adam, set_params, a broadcast), re-captures its inference graphs after a
+// bump, and never hands the cache to a handle whose arena a caller may write behind its back.  An entry is repacked when its version
+// is old or when another stream asks for it.  A training step repacks everything at first use, as before: redoing all entries ahead of
+// the step on the idle filter-gradient lane was measured and is no faster (2.60 against 2.59 ms; the 5 us packs already hide).
+struct DcPackCache {
+    float* arena = nullptr;
+    int64_t floats = 0, used = 0;
+    uint64_t version = 1;
+    struct Ent { const float* w; int wmode, N, CI, CIK, NPT, nslots, sig; int64_t off; uint64_t version; void* stream; };
+    static constexpr int MAXE = 64;
+    Ent ent[MAXE];
+    int n = 0;
+};
+
 
 // LDS pixel stride of the input tile.  A fragment read is a ds_read_b128 at (S * CIP) * l15 + 4 * kg dwords; its four 16-lane
 // groups are conflict-free exactly when S * CIP = 8 mod 16 (or 4 / 8 outright) -- enumerated over the hardware's lane groups;

@@ -97,6 +97,46 @@ bool launch_fwd2(hipStream_t s, const DcFwd& P, const DcFwd2& Q, int MI, int occ
 
 int g_dc2_last[5] = {0, 0, 0, 0, 0};   // TH, TW, units per wave, column blocks * 10 + occ, slices of the last dconv2 launch (0: the launch went to dconv_fwd_kernel)
 
+static void launch_pack(hipStream_t s, const DcFwd& P, int CIK, int nslots) {
+    const int total = nslots * CIK * P.NPT;
+    const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
+    switch (CIK) {
+        case 4: hipLaunchKernelGGL((dconv_pack_kernel<4>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+        case 8: hipLaunchKernelGGL((dconv_pack_kernel<8>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+        case 16: hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+        case 32: hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+        default: hipLaunchKernelGGL((dconv_pack_kernel<64>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
+    }
+}
+// Points P.wp at the cache slot of this (filter, shape) and says whether its packed image is current (no pack launch needed).
+// No cache / cache full: P.wp stays the caller's scratch image and the pack runs as before.
+static bool pack_cached(DcFwd& P, int CIK, int nslots, hipStream_t s) {
+    DcPackCache* pc = P.pc;
+    if (!pc || !pc->arena) return false;
+    int sig = P.ncls * 131 + P.osc * 17 + P.S;
+    for (int c = 0; c < P.ncls; ++c) {
+        sig = sig * 31 + P.cls[c].ntaps * 7 + P.cls[c].pslot0;
+        for (int e = 0; e < P.cls[c].ntaps; ++e) sig = sig * 31 + P.taps[P.cls[c].tap0 + e].wt;
+    }
+    DcPackCache::Ent* ent = nullptr;
+    for (int i = 0; i < pc->n; ++i) {
+        DcPackCache::Ent& q = pc->ent[i];
+        if (q.w == P.w && q.wmode == P.wmode && q.N == P.N && q.CI == P.CI && q.CIK == CIK && q.NPT == P.NPT && q.nslots == nslots && q.sig == sig) { ent = &q; break; }
+    }
+    if (!ent) {
+        const int64_t need = ((int64_t)nslots * CIK * P.NPT + 64 + 63) / 64 * 64;          // the image + the 16 zeros behind it
+        if (pc->n >= DcPackCache::MAXE || pc->used + need > pc->floats) return false;
+        ent = &pc->ent[pc->n++];
+        *ent = DcPackCache::Ent{P.w, P.wmode, P.N, P.CI, CIK, P.NPT, nslots, sig, pc->used, 0, nullptr};
+        pc->used += need;
+    }
+    P.wp = pc->arena + ent->off;
+    if (ent->version == pc->version && ent->stream == (void*)s) return true;
+    ent->version = pc->version;
+    ent->stream = (void*)s;
+    return false;
+}
+
 // The K-sliced, double-buffered LDS-DMA kernel of dconv2.h, for 16 / 32 input channels (either source split on a multiple of 4),
 // up to 32 filter columns in LDS beside two slice buffers, 1 or 4 tap classes.  false: not for this layer (the caller falls back).
 // Tile choice: a time model per tile on one CU --
@@ -183,18 +223,14 @@ static bool dconv_launch2(hipStream_t s, DcFwd P, int span) {
     P.tiles_y = (P.hlog + P.TH - 1) / P.TH;
     P.tiles_x = (P.wlog + P.TW - 1) / P.TW;
     P.NPT = NP; P.n0 = 0;
+    const bool packed = pack_cached(P, P.CI, nslots, s);
     Q.zeros = P.wp + (size_t)nslots * P.CI * P.NPT;
     const int ntiles = P.nimg * P.tiles_y * P.tiles_x;
     const int slots = NUM_CU * best_occ;
     const int rounds = (ntiles + slots - 1) / slots;
     const dim3 grid((unsigned)((ntiles + rounds - 1) / rounds));
     const size_t lds = 2 * slice + wall;
-    {
-        const int total = nslots * P.CI * P.NPT;
-        const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
-        if (P.CI == 16) hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, P.NPT, nslots);
-        else hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, P.NPT, nslots);
-    }
+    if (!packed) launch_pack(s, P, P.CI, nslots);
     bool ok;
 #define DC2_GO(nsl, nb2, ncls) launch_fwd2<nsl, nb2, ncls>(s, P, Q, best_mi, best_occ, grid, lds, ntiles, nslots)
     if (NSL == 1) ok = NBT == 1 ? (P.ncls == 1 ? DC2_GO(1, false, 1) : DC2_GO(1, false, 4)) : (P.ncls == 1 ? DC2_GO(1, true, 1) : DC2_GO(1, true, 4));
@@ -278,17 +314,7 @@ static void dconv_launch(hipStream_t s, DcFwd P, int span) {
     const int slots = NUM_CU * best_occ;
     const int rounds = (ntiles + slots - 1) / slots;
     const dim3 grid((unsigned)((ntiles + rounds - 1) / rounds));
-    {
-        const int total = nslots * CIK * P.NPT;
-        const dim3 pg((unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256));
-        switch (CIK) {
-            case 4: hipLaunchKernelGGL((dconv_pack_kernel<4>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
-            case 8: hipLaunchKernelGGL((dconv_pack_kernel<8>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
-            case 16: hipLaunchKernelGGL((dconv_pack_kernel<16>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
-            case 32: hipLaunchKernelGGL((dconv_pack_kernel<32>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
-            default: hipLaunchKernelGGL((dconv_pack_kernel<64>), pg, dim3(256), 0, s, P, P.NPT, nslots); break;
-        }
-    }
+    if (!pack_cached(P, CIK, nslots, s)) launch_pack(s, P, CIK, nslots);
     for (int n0 = 0; n0 < P.N; n0 += NB * 16) {
         P.n0 = n0;
         switch (CIK) {

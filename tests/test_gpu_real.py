@@ -248,3 +248,42 @@ def test_real_dropout_training_graph(T, H, W, B, keep):
     from imitation_from_observation_amd import CtxError
     with pytest.raises(CtxError, match="keep_prob"):
         T(32, 32, 32, 128, max_batch=2, keep_prob=0.5)                                # ContextSkipNew has no dropout in its graph
+
+
+def test_real_inference_follows_parameter_changes(T):
+    """The reward hook's fetches replay a captured graph whose direct-conv launches read PACKED filters kept from earlier calls (dconv.h:
+    DcPackCache).  Every way of changing parameters -- set_params, a training step -- must reach them: compare with a fresh handle."""
+    H, W, B = 36, 64, 5
+    cfg, p, fr = make(H, W, B, seed=5)
+    _, p2, _ = make(H, W, B, seed=6)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    with T(H, W, featsize=100, max_batch=B, variant="real") as tr:
+        tr.set_params(p)
+        for _ in range(4):                                  # plain call, capture, two replays
+            f_a, _ = tr.encode(fr[0])
+            pr_a, ft_a = tr.translate(fr[0], fr[1][0])
+        tr.set_params(p2)
+        for _ in range(4):
+            f_b, _ = tr.encode(fr[0])
+            pr_b, ft_b = tr.translate(fr[0], fr[1][0])
+        with T(H, W, featsize=100, max_batch=B, variant="real") as fresh:
+            fresh.set_params(p2)
+            f_ref, _ = fresh.encode(fr[0])
+            pr_ref, ft_ref = fresh.translate(fr[0], fr[1][0])
+        assert relmax(f_a, f_ref) > 1e-2                     # the two parameter sets do differ
+        np.testing.assert_array_equal(f_b, f_ref)
+        np.testing.assert_array_equal(pr_b, pr_ref)
+        np.testing.assert_array_equal(ft_b, ft_ref)
+        tr.train_step(src, ctx, tgt, lr=1e-2)                # Adam moves every parameter
+        q = tr.get_params()
+        for _ in range(3):
+            f_c, _ = tr.encode(fr[0])
+            pr_c, ft_c = tr.translate(fr[0], fr[1][0])
+        with T(H, W, featsize=100, max_batch=B, variant="real") as fresh:
+            fresh.set_params(q)
+            f_ref, _ = fresh.encode(fr[0])
+            pr_ref, ft_ref = fresh.translate(fr[0], fr[1][0])
+        assert relmax(f_c, f_b) > 1e-4
+        np.testing.assert_array_equal(f_c, f_ref)
+        np.testing.assert_array_equal(pr_c, pr_ref)
+        np.testing.assert_array_equal(ft_c, ft_ref)
