@@ -998,7 +998,7 @@ void backward(ctx_handle* h, int B, int sim_batch) {
 int forward_inference(ctx_handle* h, int B, Mode mode) {
     if (!h->use_graphs || h->prof_on || B > 64) { forward(h, B, mode); return CTX_OK; }
     ctx_handle::GraphSlot& g = h->graphs[(int)mode * (1 << 20) + (mode == MODE_TRANSLATE && h->ctx_single ? 1 << 19 : 0) + B];
-    if (g.exec && g.pack_version != h->pack.version) {               // parameters changed since the capture: its launches skip the filter packs
+    if (g.exec && h->pack.n && g.pack_version != h->pack.version) {  // parameters changed since the capture: its launches skip the filter packs
         (void)hipGraphExecDestroy(g.exec);                           // that a plain pass now has to redo (dconv.h: DcPackCache)
         g.exec = nullptr;
         g.calls = 0;
