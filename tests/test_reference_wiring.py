@@ -1,0 +1,51 @@
+"""The reference's OWN build() code of the three live model classes, executed (tests/golden/check_reference_wiring.py on the eager
+stand-in tests/golden/tf_standin.py), against oracle/ in float64: every fetch and every parameter gradient to 1e-9.
+
+Runs in the build container only (needs the reference tree; the GPU box has none: skipped there).  Pins the oracle's WIRING to the
+reference's code -- not TensorFlow's op semantics; "parity unpinned" stands."""
+import os
+import sys
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+if GOLD not in sys.path:
+    sys.path.insert(0, GOLD)
+import check_reference_wiring as crw  # noqa: E402
+import tf_standin  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(crw.reference_root(), "gym", "envs", "mujoco", "arm_shaping.py")),
+                                reason="no reference tree here (it exists in the build container only)")
+
+
+@pytest.mark.parametrize("name", list(crw.CASES))
+def test_reference_build_equals_oracle(name):
+    rows, worst, created, log = crw.CASES[name]()
+    bad = [(k, d) for k, d in rows if not d <= crw.BAR]
+    assert not bad, bad
+    # sharing: every variable is created once; the second / third pass through a scope only re-uses
+    assert len(created) == len(set(created))
+    assert {n for n, new in log if not new} <= set(created)
+
+
+def test_the_check_sees_a_wiring_error(monkeypatch):
+    """Negative control: with tf.concat's operands reversed inside the stand-in (skip tensor in front of the decoder tensor,
+    ctx code in front of the src code) the same comparison must fail by orders of magnitude."""
+    real_concat = tf_standin.concat
+    monkeypatch.setattr(tf_standin, "concat", lambda values, axis: real_concat(list(values)[::-1], axis))
+    rows, worst, _, _ = crw.case_skipnew(32, 32, 8, 2, 5)
+    assert worst > 1e-3, worst
+
+
+def test_variable_sharing_rules_are_enforced():
+    """The stand-in raises like TF1 on a second get_variable without reuse and on a reuse of a missing name."""
+    import numpy as np
+    with tf_standin.install({"a/w": np.zeros((2,)), "a/v": np.zeros((2,))}):
+        with tf_standin.variable_scope("a") as sc:
+            tf_standin.get_variable("w", [2])
+            with pytest.raises(ValueError):
+                tf_standin.get_variable("w", [2])
+            sc.reuse_variables()
+            tf_standin.get_variable("w", [2])
+            with pytest.raises(ValueError):
+                tf_standin.get_variable("v", [2])
