@@ -98,7 +98,7 @@ struct ctx_handle {
     float *wpack = nullptr, *wpackL[NLANE] = {};   // dconv's re-packed filters, one buffer per stream lane (concurrent launches)
     bool overlap = true;
     // hipGraph cache of the two inference forwards (reward hook: batch-25 calls are launch-bound): key = mode * 2^20 + B
-    struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; uint64_t pack_version = 0; };
+    struct GraphSlot { int calls = 0; hipGraphExec_t exec = nullptr; uint64_t pack_version = 0; bool self_packing = false; };
     DcPackCache pack;                // packed filters of the direct kernels, valid for pack.version (dconv.h); bumped wherever parameters change
     bool ctx_single = false;         // MODE_TRANSLATE with ONE context frame for the whole batch (`[context] * batch_size`, base.py:217-218):
                                      // `conv_context` runs on that one frame and its outputs are read by every row (forward)
@@ -400,8 +400,9 @@ int alloc_buffers(ctx_handle* h) {
     TRY(dev_alloc(h, &h->P3, (d_h4_direct(h, d, d, h->hh[1], h->ww[1], 2) ? std::min<int64_t>(B, PP_IMG) : 2 * B) * h->hh[1] * h->ww[1] * P3_LD, false));   // written by an epilogue, read by the gather: 64-bit indexing
     {   // (option "wconvt" bit 16)
         int64_t per = 0;
-        for (int k = 1; k <= 3; ++k) per = std::max<int64_t>(per, (int64_t)h->hh[5 - k] * h->ww[5 - k] * 25 * ((8 * d) >> k));
-        TRY(dev_alloc(h, &h->PP, std::min<int64_t>(B, PP_IMG) * per, false));
+        for (int k = 1; k <= 3; ++k)     // only input grids of <= 16 positions take the product route (forward: `prod`)
+            if (h->hh[5 - k] * h->ww[5 - k] <= 16) per = std::max<int64_t>(per, (int64_t)h->hh[5 - k] * h->ww[5 - k] * 25 * ((8 * d) >> k));
+        if (per) TRY(dev_alloc(h, &h->PP, std::min<int64_t>(B, PP_IMG) * per, false));
     }
     TRY(dev_alloc(h, &h->dout, 2 * B * h->npi));
     TRY(dev_alloc(h, &h->dout4, 2 * B * h->npi / 3 * 4));
@@ -532,6 +533,7 @@ void adam_end(ctx_handle* h) {
     }
     h->adam_early_on = false;
     h->adam_done.clear();
+    h->pack.version++;               // nothing packed while the update was in flight (adam_begin .. here) may pass as current afterwards
 }
 
 // the tail of the gradient arena [first, Ppad) (translate/*, deconv/*: arena order is conv_context, conv, translate, deconv) is final
@@ -998,14 +1000,19 @@ void backward(ctx_handle* h, int B, int sim_batch) {
 int forward_inference(ctx_handle* h, int B, Mode mode) {
     if (!h->use_graphs || h->prof_on || B > 64) { forward(h, B, mode); return CTX_OK; }
     ctx_handle::GraphSlot& g = h->graphs[(int)mode * (1 << 20) + (mode == MODE_TRANSLATE && h->ctx_single ? 1 << 19 : 0) + B];
-    if (g.exec && h->pack.n && g.pack_version != h->pack.version) {  // parameters changed since the capture: its launches skip the filter packs
-        (void)hipGraphExecDestroy(g.exec);                           // that a plain pass now has to redo (dconv.h: DcPackCache)
+    // A graph captured while every packed filter it uses was stale holds all its pack nodes ("self-packing": right after a training step)
+    // and is valid for any later parameters -- they are read through the arena pointer at replay.  One captured on current entries
+    // skips the packs: after a parameter change it is dropped and re-captured AT ONCE (the entries are stale now, so the new graph is
+    // self-packing): a loop that alternates training steps and reward calls replays graphs instead of falling back to plain launches.
+    if (g.exec && !g.self_packing && h->pack.n && g.pack_version != h->pack.version) {
+        (void)hipGraphExecDestroy(g.exec);
         g.exec = nullptr;
-        g.calls = 0;
+        g.calls = 1;
     }
     if (g.calls++ == 0) { forward(h, B, mode); return CTX_OK; }      // first call: plain (code objects, LDS limits, filter packs)
     if (!g.exec) {
         hipGraph_t graph = nullptr;
+        const uint64_t hits0 = h->pack.hits;
         h->capturing = true;                                         // (lanes inside the capture: option graph_lanes)
         hipError_t e = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
@@ -1015,11 +1022,13 @@ int forward_inference(ctx_handle* h, int B, Mode mode) {
         h->capturing = false;
         if (e == hipSuccess && graph) e = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
         g.pack_version = h->pack.version;
+        g.self_packing = h->pack.hits == hits0;
         if (graph) (void)hipGraphDestroy(graph);
         if (e != hipSuccess || !g.exec) {                            // capture not possible here: stay on plain launches
             (void)hipGetLastError();
             g.exec = nullptr;
             h->use_graphs = false;
+            h->pack.version++;                                       // entries the failed capture stamped "packed" exist as dropped graph nodes only
             forward(h, B, mode);
             return CTX_OK;
         }
@@ -1626,7 +1635,13 @@ int ctx_dev_scalars(ctx_handle* h, float scalars[4]) {
     return finish(h);
 }
 
-void* ctx_dev_params(ctx_handle* h) { return h ? h->arena : nullptr; }
+// The caller may WRITE through this pointer (a custom optimiser, a torch-side broadcast) without the library seeing it: from here on
+// the handle packs its direct kernels' filters in front of every launch again (DcPackCache::external) and graphs captured before are dropped.
+void* ctx_dev_params(ctx_handle* h) {
+    if (!h) return nullptr;
+    if (!h->pack.external) { h->pack.external = true; h->pack.version++; }
+    return h->arena;
+}
 void* ctx_dev_grads(ctx_handle* h) { return h ? h->arena + h->Ppad : nullptr; }
 void* ctx_dev_scalar_buf(ctx_handle* h) { return h ? h->scalars : nullptr; }
 void* ctx_stream(ctx_handle* h) { return h ? (void*)h->stream : nullptr; }

@@ -82,6 +82,8 @@ struct DcPackCache {
     float* arena = nullptr;
     int64_t floats = 0, used = 0;
     uint64_t version = 1;
+    uint64_t hits = 0;               // launches that skipped their pack (the owner tells a capture with all its pack nodes from one without)
+    bool external = false;           // the caller holds a writable pointer to the parameters (ctx_dev_params): never trust an entry
     struct Ent { const float* w; int wmode, N, CI, CIK, NPT, nslots, sig; int64_t off; uint64_t version; void* stream; };
     static constexpr int MAXE = 64;
     Ent ent[MAXE];

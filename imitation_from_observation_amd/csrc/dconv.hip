@@ -131,7 +131,7 @@ static bool pack_cached(DcFwd& P, int CIK, int nslots, hipStream_t s) {
         pc->used += need;
     }
     P.wp = pc->arena + ent->off;
-    if (ent->version == pc->version && ent->stream == (void*)s) return true;
+    if (!pc->external && ent->version == pc->version && ent->stream == (void*)s) { pc->hits++; return true; }
     ent->version = pc->version;
     ent->stream = (void*)s;
     return false;

@@ -159,6 +159,24 @@ class ModelTrainer:
     def train(self):
         basedir = self.basedir if self.basedir.endswith("/") else self.basedir + "/"
         os.makedirs(basedir, exist_ok=True)
+        rank, world, dp = self.rank, self.world, self.world > 1
+        tr = self._build()
+        if dp:
+            self._join_group(tr)
+
+        def allsum(x):
+            """sum over the ranks of a small host array (ctx_dp_allreduce_host_f64); the identity on one GPU"""
+            x = np.ascontiguousarray(x, dtype=np.float64)
+            return tr.dp_allreduce_host(x) if dp else x
+        if dp:
+            # every rank draws the same numbers: rank 0's np.random state (MT19937: 624 words + position + the cached gaussian) --
+            # BEFORE build_vdata, whose np.random.shuffle(videos) decides the video order, the subset and the train / valid split
+            st = np.random.get_state()
+            flat = np.zeros(627, np.float64)
+            if rank == 0:
+                flat[:624], flat[624], flat[625], flat[626] = st[1], st[2], st[3], st[4]
+            flat = allsum(flat)
+            np.random.set_state((st[0], flat[:624].astype(np.uint32), int(flat[624]), int(flat[625]), float(flat[626])))
         if self.vdata is None and self.videos is not None:
             from .demo_pipeline import build_vdata
             vdata, looked_at = build_vdata(self.videos, self.idims, self.nvideos, self.nlen, self.nskip, self.rescale, self.inception,
@@ -170,18 +188,9 @@ class ModelTrainer:
         if vdata.ndim != 5 or vdata.shape[2:4] != self.idims or vdata.shape[0] < self.nlen:
             raise ValueError(f"vdata must be [T >= {self.nlen}, N, {self.idims[0]}, {self.idims[1]}, 3], got {vdata.shape}")
         B, nlen = self.batch_size, self.nlen
-        rank, world, dp = self.rank, self.world, self.world > 1
         log = self.log if rank == 0 else (lambda s: None)          # one log, one set of files: rank 0's
         log(str(vdata.shape))
-        tr = self._build()
-        if dp:
-            self._join_group(tr)
         Bl, j0 = B // world, rank * (B // world)                   # this rank's rows of the global batch
-
-        def allsum(x):
-            """sum over the ranks of a small host array (ctx_dp_allreduce_host_f64); the identity on one GPU"""
-            x = np.ascontiguousarray(x, dtype=np.float64)
-            return tr.dp_allreduce_host(x) if dp else x
         n = vdata.shape[1]
         ntrain = self.ntrain
         nvalid = n - ntrain
@@ -199,14 +208,6 @@ class ModelTrainer:
         if dp and not resident:
             raise ValueError("data-parallel training runs on the device-resident sampler: the demo tensor must lie on the uint8 lattice "
                              "(k / 127.5 - 1, what train_script.py:16-19 makes of video frames)")
-        if dp:
-            # every rank draws the same batches: rank 0's np.random state (MT19937: 624 words + position + the cached gaussian)
-            st = np.random.get_state()
-            flat = np.zeros(627, np.float64)
-            if rank == 0:
-                flat[:624], flat[624], flat[625], flat[626] = st[1], st[2], st[3], st[4]
-            flat = allsum(flat)
-            np.random.set_state((st[0], flat[:624].astype(np.uint32), int(flat[624]), int(flat[625]), float(flat[626])))
         if resident:
             # only frames t < nlen are ever sampled (t = b % nlen, and frame 0 for the context); the device sampler takes
             # t = b % T with T = the uploaded tensor's length, so upload exactly nlen frames (vdata may hold more)

@@ -261,7 +261,11 @@ int ctx_set_grad_bucket_callback(ctx_handle* h, ctx_bucket_fn fn, void* user);
 int ctx_dev_adam(ctx_handle* h, float lr);
 /* Synchronises and copies {loss, simloss, recon1, recon2} of the last forward. */
 int ctx_dev_scalars(ctx_handle* h, float scalars[4]);
-void* ctx_dev_params(ctx_handle* h); /* device pointers into the arena */
+/* Device pointer to the parameters (flat, ctx_param_info order).  WRITABLE: a caller may update the weights through it (its own
+ * optimiser, a torch-side broadcast) on ctx_stream(h) or after ctx_sync(h).  The library cannot see such writes, so from the first call
+ * on it stops trusting filters it packed earlier for the direct kernels (ContextAEReal / the front end): they are re-packed in front of
+ * every launch, and inference graphs captured before the call are dropped.  Handles that never call it keep the packed-filter cache. */
+void* ctx_dev_params(ctx_handle* h);
 void* ctx_dev_grads(ctx_handle* h);
 void* ctx_dev_scalar_buf(ctx_handle* h); /* device f32[4] written by the last forward */
 void* ctx_stream(ctx_handle* h);         /* hipStream_t the kernels are enqueued on */

@@ -287,3 +287,60 @@ def test_real_inference_follows_parameter_changes(T):
         np.testing.assert_array_equal(f_c, f_ref)
         np.testing.assert_array_equal(pr_c, pr_ref)
         np.testing.assert_array_equal(ft_c, ft_ref)
+
+
+def test_real_inference_follows_writes_through_ctx_dev_params(T):
+    """ctx_dev_params hands out a WRITABLE device pointer (include/ctxtrans.h).  A caller that moves the weights through it -- a torch-side
+    broadcast, its own optimiser -- never passes the library's version counter, so the handle must stop trusting its packed filters
+    and its captured graphs from that call on: the next fetches equal a fresh handle on the new parameters, bit for bit --
+    also while the training steps in between alternate with replayed reward calls."""
+    import ctypes
+    H, W, B = 36, 64, 5
+    cfg, p, fr = make(H, W, B, seed=7)
+    _, p2, _ = make(H, W, B, seed=8)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    hip = ctypes.CDLL("libamdhip64.so")
+    with T(H, W, featsize=100, max_batch=B, variant="real") as tr, T(H, W, featsize=100, max_batch=B, variant="real") as donor:
+        tr.set_params(p)
+        for _ in range(4):                                  # plain call, capture on current entries, replays without pack nodes
+            f_a, _ = tr.encode(fr[0])
+            pr_a, ft_a = tr.translate(fr[0], fr[1][0])
+        donor.set_params(p2)
+        donor.sync()
+        lib = tr._lib
+        dst, end = lib.ctx_dev_params(tr._h), lib.ctx_dev_grads(tr._h)
+        srcp = lib.ctx_dev_params(donor._h)
+        tr.sync()
+        assert hip.hipMemcpy(ctypes.c_void_p(dst), ctypes.c_void_p(srcp), ctypes.c_size_t(end - dst), 3) == 0      # device to device, the padded arena
+        with T(H, W, featsize=100, max_batch=B, variant="real") as fresh:
+            fresh.set_params(p2)
+            f_ref, _ = fresh.encode(fr[0])
+            pr_ref, ft_ref = fresh.translate(fr[0], fr[1][0])
+        for _ in range(4):
+            f_b, _ = tr.encode(fr[0])
+            pr_b, ft_b = tr.translate(fr[0], fr[1][0])
+            assert relmax(f_a, f_b) > 1e-2
+            np.testing.assert_array_equal(f_b, f_ref)
+            np.testing.assert_array_equal(pr_b, pr_ref)
+            np.testing.assert_array_equal(ft_b, ft_ref)
+
+
+def test_real_reward_calls_between_training_steps(T):
+    """A loop that alternates training steps with the reward hook's fetches: every fetch follows the step before it (graphs captured
+    right after a step hold their own pack nodes and are replayed, not dropped -- ctxtrans.cpp: forward_inference)."""
+    H, W, B = 36, 64, 5
+    cfg, p, fr = make(H, W, B, seed=9)
+    src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
+    with T(H, W, featsize=100, max_batch=B, variant="real") as tr, T(H, W, featsize=100, max_batch=B, variant="real") as fresh:
+        tr.set_params(p)
+        for step in range(5):
+            tr.train_step(src, ctx, tgt, lr=1e-2)
+            fresh.set_params(tr.get_params())
+            f_ref, _ = fresh.encode(fr[0])
+            pr_ref, ft_ref = fresh.translate(fr[0], fr[1][0])
+            for _ in range(2):
+                f, _ = tr.encode(fr[0])
+                pr, ft = tr.translate(fr[0], fr[1][0])
+                np.testing.assert_array_equal(f, f_ref)
+                np.testing.assert_array_equal(pr, pr_ref)
+                np.testing.assert_array_equal(ft, ft_ref)

@@ -149,6 +149,55 @@ def test_two_rank_trainer_equals_the_single_process_reference_loop(tmp_path):
             np.testing.assert_array_equal(read_clip(f"{base}40/__{kk}{tag}.gif"), read_clip(f"{one}40/__{kk}{tag}.gif"))
 
 
+def _videos_worker(rank, world, port, q, base):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imitation_from_observation_amd.trainer import ModelTrainer
+    rng = np.random.default_rng(9)
+    videos = [rng.integers(1, 256, (51, 24, 24, 3), dtype=np.uint8) for _ in range(NVID + 3)]    # more videos than nvideos: a SUBSET is chosen
+    np.random.seed(7 if rank == 0 else 1234 + rank)                 # unsynchronised streams, as separate processes have
+    model = OracleDPModel(3, rank, world)
+    lines = []
+    ModelTrainer((H, W), NVID, NTRAIN, B, "ContextSkipNew", 6, 5, NLEN, 17, vdata=None, videos=videos, basedir=base, translator=model,
+                 log=lines.append, rank=rank, world=world).train()
+    q.put((rank, model.demos.copy(), o.flatten(model.p, CFG), lines))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_trainer_builds_the_same_demo_tensor_from_videos(tmp_path):
+    """ModelTrainer(videos=..., world=2): build_vdata's np.random.shuffle(videos) (train_script.py:66) picks the video order, the subset
+    and the train / valid split -- rank 0's np.random state must reach the other ranks BEFORE it, or the ranks train on different
+    demo tensors with shared index arrays.  Both ranks must hold rank 0's tensor = the single-process one."""
+    world = 2
+    base = str(tmp_path / "dpv") + "/"
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = _free_port()
+    procs = [ctxm.Process(target=_videos_worker, args=(r, world, port, q, base)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=500) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, d0, p0, lines0), (_, d1, p1, lines1) = got
+    np.testing.assert_array_equal(d0, d1)                           # the same videos, in the same order, on every rank
+    np.testing.assert_array_equal(p0, p1)
+    assert lines1 == []
+    # the single-process pipeline on rank 0's stream
+    from imitation_from_observation_amd.demo_pipeline import build_vdata
+    rng = np.random.default_rng(9)
+    videos = [rng.integers(1, 256, (51, 24, 24, 3), dtype=np.uint8) for _ in range(NVID + 3)]
+    np.random.seed(7)
+    vdata = build_vdata(videos, (H, W), NVID, NLEN, 17, True, False)
+    np.testing.assert_allclose(d0, np.asarray(vdata, np.float64)[:NLEN], atol=1e-6)
+    saved = [f for f in os.listdir(base) if f.startswith("vdata_strike")]
+    assert len(saved) == 1                                          # rank 0 alone writes the tensor
+
+
 def test_trainer_refuses_bad_data_parallel_arguments(tmp_path):
     from imitation_from_observation_amd.trainer import ModelTrainer
     with pytest.raises(ValueError, match="multiple of world"):
