@@ -261,6 +261,7 @@ bool convt3_direct_ok(int c1, int c2, int hin, int win, int stride) {
 // out[nimg][S*hin][S*win][3] = conv2d_transpose(concat(x1, x2[img % nmod2]), w[5][5][3][c1 + c2], stride S, SAME) + bias
 void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int c2, int nmod2, int nimg, int hin, int win, int stride,
                    const float* w, const float* bias, float* out) {
+    if (convt3_mfma_ok(c1, c2, hin, win, stride, nimg)) { convt3_mfma(s, x1, c1, x2, nmod2, nimg, hin, win, stride, w, bias, out); return; }
     Ct3 A{};
     A.x1 = x1; A.c1 = c1; A.x2 = x2; A.c2 = c2; A.nmod2 = nmod2; A.CI = c1 + c2; A.hin = hin; A.win = win; A.nimg = nimg;
     A.w = w; A.bias = bias; A.out = out;

@@ -47,7 +47,7 @@ void ensure_dyn_lds(const void* kernel, size_t bytes) {
 namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[OPT_COUNT] = {
-    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 9}, {"wconvt", 31}, {"direct3", 15}, {"dconv", 3},
+    {"overlap", -1}, {"graphs", 1}, {"graph_lanes", 1}, {"posmajor", 1}, {"xcd_swizzle", 7}, {"balance", 9}, {"wconvt", 31}, {"direct3", 31}, {"dconv", 3},
     {"rchain", 1}, {"early_adam", 1}, {"cnn_lanes", -1}, {"cnn_dconv", 1}, {"cnn_stem4", 1}, {"trace_launch", 0}, {"adam_prio", 2},
 };
 }  // namespace

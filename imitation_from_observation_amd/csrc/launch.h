@@ -123,6 +123,12 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
 bool convt3_direct_ok(int c1, int c2, int hin, int win, int stride);
 void convt3_direct(hipStream_t s, const float* x1, int c1, const float* x2, int c2, int nmod2, int nimg, int hin, int win, int stride,
                    const float* w, const float* bias, float* out);
+// The same layer on the MATRIX cores (convt3m.hip): P[pixel][(ky)(kx, c)] as 16-column MFMA blocks per filter row, A operand straight
+// from global memory, P kept in an LDS ring and gathered into output rows inside the block -- one pass over the input, for launches of
+// >= 128 images (training batches).  convt3_direct dispatches to it where convt3_mfma_ok (option direct3 bit 16).
+bool convt3_mfma_ok(int c1, int c2, int hin, int win, int stride, int nimg);
+void convt3_mfma(hipStream_t s, const float* x1, int c1, const float* x2, int nmod2, int nimg, int hin, int win, int stride,
+                 const float* w, const float* bias, float* out);
 constexpr int P3_LD = 80;                   // row stride of P (75 used)
 constexpr int PP_IMG = 32;                  // most images of a launch that takes the product + gather route of convt_product
 void convt3_product(hipStream_t s, const KmCat2& a, const float* w, int cb, float* P, int M, SplitWs ws);

@@ -17,7 +17,7 @@ enum Opt {
                        // grids instead (wins over 2); 4 load-balanced taps in the filter gradient
     OPT_WCONVT,        // bits: 1 LDS-resident transposed conv (wconvt.hip), 2 row blocks on 4x4 grids, 4 row blocks on 8x8 grids, 8 column-uniform waves,
                        // 16 inference launches of <= 32 images as one product + a gather (launch.h: convt_product)
-    OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3)
+    OPT_DIRECT3,       // bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass (convt3), 16 ... on the matrix cores at >= 128 images (convt3m)
     OPT_DCONV,         // bits: 1 ContextAEReal in f32 on the narrow-channel direct kernels (dconv.h), 2 their forward-type launches on the K-sliced
                        // double-buffered LDS-DMA kernel (dconv2.h) where it applies
     OPT_RCHAIN,        // 1: ContextAEReal's FC middle in three launches (rchain.hip)

@@ -127,7 +127,8 @@ const char* ctx_last_error(const ctx_handle* h);
  *                    8 Z-order (2-D compact) runs on larger grids instead (wins over 2); 4 load-balanced taps in the filter gradient
  *   wconvt      31   bits: 1 LDS-resident transposed conv, 2 / 4 row blocks on 4x4 / 8x8 grids, 8 column-uniform waves (4x4),
  *                    16 inference launches of <= 32 images as one product + a gather
- *   direct3     15   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass  [fixed at create]
+ *   direct3     31   bits: 1 3-channel layers on the direct kernels, 2 c3conv, 4 c3wgrad, 8 d_h4 forward in one pass, 16 d_h4 forward on the
+ *                    matrix cores at >= 128 images (convt3m.hip)  [fixed at create]
  *   dconv        3   bits: 1 ContextAEReal in f32 on the narrow-channel direct kernels, 2 the K-sliced LDS-DMA forward kernel     [fixed at create]
  *   rchain       1   ContextAEReal's FC middle in three launches
  *   early_adam   1   Adam's slices beside the remaining backward in the fused ContextSkipNew steps (bit-identical; -0.06 ms)
