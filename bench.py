@@ -418,14 +418,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
-    if torch.cuda.device_count() < world:
+    # BENCH_ONE_GPU=1 (tests/test_gpu_bench_ranks.py, tools/scale_check.sh): the N ranks of the REAL --gpus N code path share device 0 --
+    # the torch group runs on gloo (two ranks cannot share a device under RCCL) and ctx_dp_* talks to whatever CTX_RCCL_LIB names (the
+    # shared-memory stand-in of tests/fake_rccl).  It exercises spawn -> group -> ctx_dp_init -> timed steps -> comm block -> one JSON
+    # line before an 8-GPU node sees that path first; the line is marked and its value is NOT a scaling figure.
+    one_gpu = os.environ.get("BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
+    elif torch.cuda.device_count() < world:
         raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} visible")
+    red_dev = "cpu" if one_gpu else "cuda"                          # where the group's small reductions live
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":     # (the env switch: a one-rank RCCL group, to exercise the N > 1 code on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()
         # RCCL prints its version banner through C stdio, which is block-buffered on a pipe and would otherwise land AFTER the
         # JSON line at exit: flush it now so that the JSON line is the last line of stdout
@@ -447,7 +458,7 @@ def main():
         except Exception as e:                                  # noqa: BLE001  (a missing / unloadable librccl on this rank)
             sys.stderr.write(f"bench.py: rank {rank}: RCCL behind the C ABI unavailable ({e!r}); asking for the torch client\n")
             ok = 0
-        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        flag = torch.tensor([ok], device=red_dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             # no silent change of client: the number would be another schedule's (one all-reduce after backward, no overlap).  Ask for
@@ -488,7 +499,7 @@ def main():
         barrier()
         dt_ = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dt_], device="cuda", dtype=torch.float64)
+            tmax = torch.tensor([dt_], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_ = float(tmax.item())
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
@@ -509,7 +520,7 @@ def main():
         barrier()
         dts = time.perf_counter() - t0
         if world > 1:
-            tmax = torch.tensor([dts], device="cuda", dtype=torch.float64)
+            tmax = torch.tensor([dts], device=red_dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dts = float(tmax.item())
         sustained = {"steps": n_sus, "seconds": dts, "ms_per_step": 1e3 * dts / n_sus, "frames_per_s": n_sus * B * world / dts}
@@ -544,7 +555,7 @@ def main():
             barrier()
             dts = time.perf_counter() - t0
             if world > 1:
-                tmax = torch.tensor([dts], device="cuda", dtype=torch.float64)
+                tmax = torch.tensor([dts], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 dts = float(tmax.item())
             sampled = {"ms_per_step": 1e3 * dts / args.steps, "frames_per_s": args.steps * Bg / dts, "steps": args.steps,
@@ -569,6 +580,7 @@ def main():
                                  "torch": "torch.distributed all-reduce between ctx_dev_forward_backward and ctx_dev_adam",
                                  "single": "none (one rank)"}[dp_client]},
         "loss_after": scal["loss"],
+        **({"one_gpu_stand_in": True, "note": "BENCH_ONE_GPU=1: the N ranks time-share ONE device (torch group on gloo, ctx_dp_* through CTX_RCCL_LIB): a code-path run, NOT a scaling figure"} if one_gpu else {}),
         "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None, "sustained": sustained,
         "sampled": sampled,
         "step_ms_hip_events": step_events,          # rank 0's stream; `ms_per_step` / `value` are the wall-clock mean, max over ranks
@@ -653,7 +665,9 @@ def main():
             drain()
             ar_ms = 1e3 * (time.perf_counter() - t0) / nrep
             nbytes = trl.n_params * 4
-            line["comm"] = {"payload_MB": nbytes / 1e6, "allreduce_ms": ar_ms, "compute_ms_per_step": compute_ms,
+            worlds = [None] * world
+            dist.all_gather_object(worlds, int(trl.dp_world()[1]) if dp_client == "cabi" else world)
+            line["comm"] = {"payload_MB": nbytes / 1e6, "allreduce_ms": ar_ms, "compute_ms_per_step": compute_ms, "ctx_dp_world_by_rank": worlds,
                             "busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if world > 1 else None,
                             "client": dp_client, "overlap": dp_client == "cabi" or os.environ.get("CTX_DP_OVERLAP", "0") == "1"}
         except Exception as e:                      # diagnostics must never cost the bench line

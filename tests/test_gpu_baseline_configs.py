@@ -102,11 +102,14 @@ def test_config1_batch256_against_the_float64_oracle_fixture(T):
               {k: tuple(float(f"{x:.1e}") for x in v) for k, v in report.items()})
         # d_h4 sits upstream of every lrelu' mask: no flip can reach it.  Everything else carries the flips reported above;
         # north_star's budget is 1e-3 relative.
+        # Un-aligned bars = what this build measures + 30 % (round 6: worst sample rel-L2 1.3e-3 -- the `conv` encoder behind four flipped
+        # activations --, projections 1.5e-3, norms 2.8e-4; profiles/round6_c_unaligned_gradient_deviation.txt).  That these are flips and
+        # nothing else: the aligned comparison below / tests/test_gpu_parity.py::test_adam_trajectory_branch_aligned (<= 2e-6 / 1e-4).
         for n, (samp, proj, nrm) in report.items():
             tight = n.startswith("deconv/d_h4")
-            assert samp <= (1e-5 if tight else 2e-3), (n, samp, proj, nrm)
-            assert proj <= (1e-5 if tight else 3e-3), (n, samp, proj, nrm)               # 16 projections: +-35 % on the estimate
-            assert nrm <= (1e-5 if tight else 1e-3), (n, samp, proj, nrm)
+            assert samp <= (1e-5 if tight else 1.5e-3), (n, samp, proj, nrm)
+            assert proj <= (1e-5 if tight else 2e-3), (n, samp, proj, nrm)               # 16 projections: +-35 % on the estimate
+            assert nrm <= (1e-5 if tight else 4e-4), (n, samp, proj, nrm)
 
 
 # ------------------------------------------------------------------------------------------------ configs[2]
@@ -242,8 +245,8 @@ def test_config3_inception2_batch64_per_gpu_through_linearity(T):
             n = int(np.prod(shape))
             worst[name] = rel_l2(full[off:off + n], acc[off:off + n])
         print("batch 64 vs sum of 8 shards, rel-L2 per tensor:", {k: float(f"{v:.1e}") for k, v in worst.items()})
-        assert max(worst.values()) <= 2e-3, worst                                       # lrelu' flips between differently ordered f32 sums
-        assert worst["deconv/d_h4/w"] <= 1e-5                                           # upstream of every mask
+        # measured 8.0e-7 (no activation changes sides between the two summation orders on this fixture); one lrelu' flip would show as ~1e-3
+        assert max(worst.values()) <= 2e-6, worst
         s = tr.train_step(*feats, lr=1e-4)
         assert np.isfinite(s["loss"]) and abs(s["loss"] - big["loss"]) <= 1e-6 * big["loss"]
 
@@ -275,9 +278,11 @@ def test_config4_context_ae_real_at_64x64_matches_oracle(T, B):
         assert relmax(tz, res["translated_z"]) < 1e-5 and relmax(iz, res["input_z"]) < 1e-5
         tr.train_step(src, ctx, tgt, lr=0.0)
         gg = tr.get_grads()
+        print(f"ContextAEReal 64x64 B = {B}: worst un-aligned gradient deviation max-norm {max(relmax(gg[n], g[n]) for n in g):.2e}, rel-L2 {max(rel_l2(gg[n], g[n]) for n in g):.2e}")
         for n in g:
-            assert relmax(gg[n], g[n]) < (1e-4 if B == 2 else 1e-3), n
-            assert rel_l2(gg[n], g[n]) < (1e-4 if B == 2 else 2e-3), n
+            # un-aligned; measured + 30 %: B = 2 9.6e-7 / 8.6e-7, B = 32 6.4e-4 / 8.7e-5 (a flipped activation in the position-major launches)
+            assert relmax(gg[n], g[n]) < (2e-6 if B == 2 else 8.5e-4), n
+            assert rel_l2(gg[n], g[n]) < (2e-6 if B == 2 else 1.2e-4), n
         if B == 2:
             pred, feat = tr.translate(fr[0], fr[1][0])
             c0 = np.broadcast_to(o.preprocess_u8(fr[1][0]), src.shape).astype(np.float64)

@@ -134,9 +134,12 @@ def test_inception2_at_8x8x2048_batch25_against_the_float64_fixture(T):
               {k: tuple(float(f"{x:.1e}") for x in v) for k, v in report.items()})
         for n, (samp, proj, nrm) in report.items():
             tight = n.startswith("deconv/d_h4")                                         # upstream of every lrelu' mask
-            assert samp <= (1e-5 if tight else 1e-2), (n, samp, proj, nrm)
-            assert proj <= (1e-5 if tight else 3e-3), (n, samp, proj, nrm)
-            assert nrm <= (1e-5 if tight else 1e-3), (n, samp, proj, nrm)
+            # un-aligned bars = measured + 30 % (round 6: 1.4e-4 / 1.1e-4 / 1.2e-5, the `conv` encoder's tensors; round 5's build had flips
+            # worth 2.3e-3 here -- which activations sit within rounding of zero moves with every summation order, so a kernel change may
+            # move these: the aligned comparison (2) below is the invariant one)
+            assert samp <= (1e-5 if tight else 2e-4), (n, samp, proj, nrm)
+            assert proj <= (1e-5 if tight else 1.5e-4), (n, samp, proj, nrm)
+            assert nrm <= (1e-5 if tight else 2e-5), (n, samp, proj, nrm)
         # (2) the oracle re-run with the device's branches
         from tests._align import align_gen_cache
         p64 = {k: v.astype(np.float64) for k, v in p32.items()}
@@ -278,8 +281,8 @@ def test_skipnew_48x48_batch64_equals_the_sum_of_its_shards(T):
             n = int(np.prod(shape))
             worst[name] = rel_l2(full[off:off + n], acc[off:off + n])
         print("48x48 batch 64 vs sum of 8 shards, rel-L2 per tensor:", {k: float(f"{v:.1e}") for k, v in worst.items()})
-        assert max(worst.values()) <= 2e-3, worst                                       # lrelu' flips between differently ordered f32 sums
-        assert worst["deconv/d_h4/w"] <= 1e-5                                           # upstream of every mask
+        assert max(worst.values()) <= 8e-4, worst                                       # lrelu' flips between differently ordered f32 sums: measured 5.9e-4 + 30 %
+        assert worst["deconv/d_h4/w"] <= 1e-6                                           # upstream of every mask (measured 9.2e-8)
 
 
 # ------------------------------------------------------------------------------------------------ (c) loss switches, other variants

@@ -18,14 +18,22 @@ PY
 )
 NS=${@:-1 2 4 8}
 echo "GPUs visible: $NGPU"
+# ONE_GPU=1: the same commands with every rank on device 0 (bench.py BENCH_ONE_GPU=1: torch group on gloo, ctx_dp_* through the shared-memory
+# stand-in of tests/fake_rccl) and a small batch -- a dry run of the N > 1 code path on a 1-GPU box; the table it prints is NOT a scaling curve
+EXTRA=""
+if [ "${ONE_GPU:-0}" = "1" ]; then
+  export BENCH_ONE_GPU=1 CTX_RCCL_LIB=$PWD/tests/fake_rccl/libfakerccl.so FAKE_RCCL_TIMEOUT_S=300
+  NGPU=8; EXTRA="--batch 8 --sustained-s 0.2 --kernel-iters 1"; STEPS=${STEPS:-3}
+  echo "ONE_GPU=1: N ranks time-share device 0 -- code-path run, not a scaling measurement"
+fi
 # every rank's handle must report the world it was initialised with (one process per GPU, RCCL behind the C ABI)
 for N in $NS; do
   [ "$N" -gt "$NGPU" ] && { echo "N=$N: skipped ($NGPU GPUs visible)"; continue; }
-  if [ "$N" -gt 1 ]; then
+  if [ "$N" -gt 1 ] && [ "${ONE_GPU:-0}" != "1" ]; then
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((29600 + N)) tools/dp_world_check.py > $OUT/world_$N.txt 2>&1 \
       && echo "N=$N: ctx_dp_world ok on every rank: $(grep -c 'world ok' $OUT/world_$N.txt) ranks" || { echo "N=$N: ctx_dp_world check FAILED (see $OUT/world_$N.txt)"; tail -5 $OUT/world_$N.txt; }
   fi
-  python bench.py --gpus $N --steps ${STEPS:-30} --warmup 10 --no-cpu-baseline --no-secondary --no-split-leg > $OUT/bench_$N.json 2> $OUT/bench_$N.err || { echo "N=$N: bench.py failed"; tail -5 $OUT/bench_$N.err; }
+  python bench.py --gpus $N --steps ${STEPS:-30} --warmup 10 --no-cpu-baseline --no-secondary --no-split-leg $EXTRA > $OUT/bench_$N.json 2> $OUT/bench_$N.err || { echo "N=$N: bench.py failed"; tail -5 $OUT/bench_$N.err; }
 done
 python - <<'PY'
 import glob, json, os
