@@ -5,7 +5,7 @@
 //   dw[tap][a][n] = sum over images and small-grid pixels p of  big[S p + tap - pad][a] * small[p][n]
 //
 // GEMM rows m = 3 tap + a (75 of 80 used), columns n, K = pixels.  The generic narrow-channel kernel spends 4.8 vector-ALU
-// instructions per MFMA on run-time tile geometry and keeps the matrix pipe 44 % busy (PMC, profiles/round3_b_pmc_*): 0.20 ms for
+// instructions per MFMA on run-time tile geometry and keeps the matrix pipe 44 % busy (PMC, profiles/archive/round3_b_pmc_*): 0.20 ms for
 // ContextSkipNew's d_h4 against ~0.08 ms of either matrix or HBM time.  Here everything about a tile is a compile-time constant:
 //   * a tile is 128 small-grid pixels (4 rows x 32 or 8 x 16); wave w owns the pixels of row(s) w and ALL 16 NB columns, so its
 //     K loop is 32 fully unrolled steps of four x-adjacent pixels: 5 + NB ds_read_b32 at literal offsets from two per-lane base

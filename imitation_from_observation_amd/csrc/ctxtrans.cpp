@@ -490,7 +490,7 @@ constexpr int LANE_CTX = 0, LANE_DW = 1;
 // stream holds one, compute stream and two lanes the other three, and `adam_stream` lands on the filter-gradient lane's queue, so the
 // slices run beside the dx chain but in turn with the filter gradients.  With GPU_MAX_HW_QUEUES=8 it has its own queue and the step
 // loses another 0.05 ms, but ContextAEReal's small launches then run truly side by side and get slower (2.71 -> 3.11 ms), so the
-// library does not ask for it (profiles/round4_e_early_adam_queues.txt).  ON by default (option "early_adam"; read at every step).
+// library does not ask for it (profiles/archive/round4_e_early_adam_queues.txt).  ON by default (option "early_adam"; read at every step).
 void adam_launch(ctx_handle* h, hipStream_t s, int64_t first, int64_t end) {
     adam(s, h->arena + first, h->arena + h->Ppad + first, h->arena + 2 * h->Ppad + first, h->arena + 3 * h->Ppad + first, end - first,
          h->adam_lr_t, 0.9f, 0.999f, 1e-8f);
@@ -1258,7 +1258,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     if (rc == CTX_OK) {
         // -1 = by size: the lanes pay where the launches are long enough to hide a cross-queue hop (measured 11.5 us each; a step has ~25
         // of them).  On ContextAEInception2's 2x2 maps they gain 0.07 ms of 2.7 alone and LOSE 0.23 ms of 6.85 behind the front end on a
-        // caller's stream, where lane and compute stream came to share a hardware queue (profiles/round4_e_config4_lanes.txt).
+        // caller's stream, where lane and compute stream came to share a hardware queue (profiles/archive/round4_e_config4_lanes.txt).
         if (h->opt.v[OPT_OVERLAP] < 0) h->opt.v[OPT_OVERLAP] = !(h->gen && h->H * h->W < 64);
         h->overlap = h->opt.v[OPT_OVERLAP] != 0;
         h->use_graphs = h->opt.v[OPT_GRAPHS] != 0;
@@ -1274,7 +1274,7 @@ int ctx_create_ex(const ctx_config* cfg, int device, void* stream, void* arena, 
     // The Adam stream in its own PRIORITY class (option adam_prio, default 2 = low for exact-f32 handles, normal for split-bf16 ones, whose
     // step -- in a process that also holds an f32 handle -- went from 8.0 to 9.2 ms with it: which streams share a queue is the runtime's choice): a priority class has its own hardware queues, so the
     // slices of the early update no longer take turns with the filter-gradient lane on a shared queue (step -0.03..-0.05 ms in two A/B
-    // pairs, profiles/round4_e_early_adam_queues.txt).  Its launches are 80-230 us HBM-bound kernels: the slowdown seen with prioritised
+    // pairs, profiles/archive/round4_e_early_adam_queues.txt).  Its launches are 80-230 us HBM-bound kernels: the slowdown seen with prioritised
     // LANES (5 us kernels beside another class's) does not apply.
     if (h->opt.v[OPT_ADAM_PRIO] == 2) h->opt.v[OPT_ADAM_PRIO] = h->cfg.precision == CTX_PREC_F32 ? 1 : 0;     // (2 = by precision; reads back resolved)
     if (rc == CTX_OK && (hipStreamCreateWithPriority(&h->adam_stream, hipStreamNonBlocking, h->opt.v[OPT_ADAM_PRIO]) != hipSuccess ||

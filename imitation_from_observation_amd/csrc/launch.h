@@ -33,7 +33,7 @@ void ensure_dyn_lds(const void* kernel, size_t bytes);
 // un-captured launch of that shape creates the entry.
 const uint16_t* balanced_order(const int* weight, int nprob, int nbins, int tiles_per_problem, hipStream_t stream);
 const uint16_t* morton_order(int gh, int gw, hipStream_t stream);      // Z-order walk of a grid of problems (kernels.hip)
-// CTX_BALANCE bits (whole-step A/B, profiles/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (the 4x4
+// CTX_BALANCE bits (whole-step A/B, profiles/archive/round4_a_ab_balance.txt): 1 = position-major conv on grids of <= 16 positions (the 4x4
 // layers: d_h1's input gradient 0.675 -> 0.59 ms, h3_conv forward 0.352 -> 0.316); 2 = on larger grids too (with the pair-aware order
 // inside a run: -0.03 ms of step; before it the scattered positions of an 8x8 grid cost more L2 misses than the 7.5 % imbalance);
 // 4 = the rectangle-ordered filter gradient's 25 taps (+0.05 ms of step: its launches run several rounds and balance themselves);

@@ -3,7 +3,7 @@
 //
 // With featsize 100 these layers are 0.35 GFLOP forward -- nothing -- but each one is an implicit-GEMM launch plus a split-K
 // combine (and, backward, two column-sum launches): 114 us of the forward's critical path and 245 us of the backward's on a
-// 2.8 ms step, every launch a 15-20 us floor (profiles/round3_b_timeline_context_ae_real.txt).  Every FC layer acts on a ROW, and
+// 2.8 ms step, every launch a 15-20 us floor (profiles/archive/round3_b_timeline_context_ae_real.txt).  Every FC layer acts on a ROW, and
 // the rows of one (target, source, context) triple never meet another triple's before the filter gradients, so:
 //   rchain_fwd   a block takes TB = 2 triples (6 encoder rows) through all five layers, activations in LDS, weights read
 //                straight from L2 (1.2 MB, shared by all blocks);

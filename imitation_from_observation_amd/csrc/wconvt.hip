@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_kernel(const WcT P) {
 //
 // `wconvt_kernel` forms all 25 taps at every position; on a 4x4 / 8x8 grid 28 % / 14 % of those products read the zero halo (a
 // whole-step A/B with the loop cut to 18 / 21 taps -- wrong results, right amount of work -- put the ceiling of skipping them at
-// -0.37 / -0.59 ms of the 13.4 ms step; profiles/round4_a_ab_upper_bounds.txt).  An MFMA's 32 columns are 32 POSITIONS, so a tap can
+// -0.37 / -0.59 ms of the 13.4 ms step; profiles/archive/round4_a_ab_upper_bounds.txt).  An MFMA's 32 columns are 32 POSITIONS, so a tap can
 // only be dropped where it is invalid for all of them.  Here a block owns ONE GRID ROW r of 64 / WS images (64 positions per parity
 // class) x 64 output channels, so "tap (dy, dx) reads input row r + dy" is block-uniform: a block of row 0 runs the 15 taps with
 // dy >= 0, one of the last row the 20 with dy <= 0, interior rows all 25 -- (15 + 20 + 25 (HS - 2)) / (25 HS) of the products:
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WC_THREADS, 2) void wconvt_row_kernel(const WcT P) 
     // A launch of these layers is about one round of resident blocks (two per CU), so its time is that of the slowest CU: with the
     // long blocks dispatched first every CU gets a long one, and the short ones fill the second slots -- a (25, 15..20)-tap pair
     // shares the matrix pipe instead of two 25-tap blocks on one CU and two short ones on another (whole step 13.32 -> 13.20 ms against
-    // the group-major order, profiles/round4_a_ab_row_blocks.txt).
+    // the group-major order, profiles/archive/round4_a_ab_row_blocks.txt).
     const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
     const int nig = (P.nimg + G::IMGT - 1) / G::IMGT, nigl = (nig + 7) / 8;
     const int nt = l % P.gn, q = l / P.gn;
@@ -602,7 +602,7 @@ void wconvt_fwd(hipStream_t s, const float* s1, int c1, const float* s2, int c2,
     int ks = 1;
     const int slots400 = dev_info().cus * 2 * 25 / 32;                     // ~ 78 % of the resident block slots (400 of 512 on MI355X)
     // STARVED launches (the reward hook's batch of 25: d_h1 offers 16-32 blocks to 256 CUs and each walks 32 slices x 25 taps alone --
-    // 0.45 ms of a 1.4 ms translate call, profiles/round4_b_reward_trace_before.txt): 32-wide column tiles and the channel slices over
+    // 0.45 ms of a 1.4 ms translate call, profiles/archive/round4_b_reward_trace_before.txt): 32-wide column tiles and the channel slices over
     // up to 16 blocks, whatever the grid.
     const bool starved = ntile * (ca / 64) * 2 <= dev_info().cus;
     if (starved) {
