@@ -503,7 +503,7 @@ void adam_begin(ctx_handle* h, float lr) {
     h->adam_done.clear();
     h->pack.version++;               // the parameters change in this step: packed filters are stale from here on
     // (only where the update is worth hiding: ContextAEReal's 1.2 M parameters are a 7 us update, and the slices' events and queue hops
-    // among its 5-30 us launches cost 0.4 ms of a 2.6 ms step -- tools/secondary_gap.py: 3.00 -> 2.58 ms, round 5)
+    // among its 5-30 us launches cost 0.4 ms of a 2.6 ms step -- bench.py's secondary leg against forward_backward + adam on one box: 3.00 -> 2.58 ms, round 5)
     h->adam_early_on = env_on && h->adam_stream && use_lanes(h) && h->P >= (4ll << 20);
 }
 // [first, end) is final in the order of the CURRENT stream plus (lane >= 0) of that side lane
@@ -1045,7 +1045,7 @@ int check_B(ctx_handle* h, int B) {
 
 // Device -> pageable host, in pieces of 16 MiB so that no single transfer leaves the runtime's staged path.  (The "B = 1000
 // cliff" of ctx_encode -- 49 MB of float frames handed back -- turned out NOT to be this copy: it was the caller's fresh > 32 MB
-// numpy array faulting its pages in while the copy landed; tools/encode_cliff.py, Translator.encode(out=...).)
+// numpy array faulting its pages in while the copy landed; profiles/archive/round2_b_encode_cliff.txt, Translator.encode(out=...).)
 int copy_d2h(ctx_handle* h, void* dst, const void* src, size_t bytes) {
     constexpr size_t PIECE = 16u << 20;
     for (size_t o = 0; o < bytes; o += PIECE)

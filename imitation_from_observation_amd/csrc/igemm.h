@@ -15,7 +15,7 @@
 // Block = WM x WN waves, block tile (32*MI*WM) x (32*NI*WN), K staged KC = 32 at a time through a double-buffered
 // LDS ring with ONE barrier per chunk.  The shipped 128x128 tile runs EIGHT waves (8 x 64x32 or 8 x 32x64, chosen per
 // loader pair in gemm_launch.h): at two blocks per CU that is four waves per SIMD, which hides the load latency
-// better than four 64x64 waves did (-6..-20 % per kernel).  Measured anatomy on MI355X (tools/mfma_ablate.hip): the
+// better than four 64x64 waves did (-6..-20 % per kernel).  Measured anatomy on MI355X (an ablation micro-benchmark of round 1, notebook section 5): the
 // MFMA stream alone runs at the 152 TF/s pipe peak (2.32 GHz); what costs is anything that sits BETWEEN a barrier
 // and the first MFMA.  Therefore
 //   * loaders are branch-free -- out-of-range lanes (SAME padding, ragged edges) get an out-of-range buffer offset

@@ -768,8 +768,8 @@ void colsum(hipStream_t s, const float* x, int64_t rows, int C, float* scratch, 
     const int rpb = NTHREADS / tpr;
     int nsl = (int)((rows + (int64_t)rpb * 8 - 1) / ((int64_t)rpb * 8));
     // 128 slabs, not the 512 that make this kernel fastest alone (0.30 vs 0.26 ms per step): it runs on the side lane beside
-    // the MFMA-bound chain, and the fewer CU slots it takes the less it slows that chain (whole step 14.50 vs 14.68 ms; tools/colsum_ab.sh)
-    constexpr int cap = 128 < COLSUM_SPLITS ? 128 : COLSUM_SPLITS;   // (512 row slabs make the column sums faster alone and the step slower: round 1, tools/colsum_ab.sh)
+    // the MFMA-bound chain, and the fewer CU slots it takes the less it slows that chain (whole step 14.50 vs 14.68 ms)
+    constexpr int cap = 128 < COLSUM_SPLITS ? 128 : COLSUM_SPLITS;   // (512 row slabs make the column sums faster alone and the step slower: round 1)
     if (nsl > cap) nsl = cap;
     if (nsl < 1) nsl = 1;
     const int64_t rows_per = (rows + nsl - 1) / nsl;

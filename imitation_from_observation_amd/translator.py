@@ -45,7 +45,7 @@ def _fp(a):
 class _ResultPool:
     """Result arrays of the inference fetches, recycled.  A result above glibc's mmap threshold (32 MB: B >= 683 frames of 64x64x3 f32)
     is a FRESH mapping every time numpy allocates it, whose pages fault in while the device copy lands -- 4.4 of the 8.5 ms of an
-    `encode` call at B = 1000 (tools/encode_cliff.py).  The pool hands out an array it made before as soon as nobody else holds it
+    `encode` call at B = 1000 (profiles/archive/round2_b_encode_cliff.txt).  The pool hands out an array it made before as soon as nobody else holds it
     any more (its reference count is back to the pool's own), so a caller that drops or overwrites the previous result -- the reward
     hook's loop -- gets warm pages, and a caller that keeps results gets fresh arrays exactly as before: no aliasing either way.
     Only arrays of >= `min_bytes` are pooled (small ones come from malloc's free lists and are warm anyway)."""

@@ -180,7 +180,7 @@ def test_adam_trajectory_matches_oracle(T, steps):
         mm, vv, step = tr.get_adam_state()
         assert step == steps
         # (after three steps the moments carry the gradients of steps 2 and 3, i.e. of the slightly different models: the same 2-3e-3
-        # as the update -- tools/dbg_adam_traj.py prints it per tensor and step: <= 5e-5 after step 1, 3e-4 after step 2 in the tensors
+        # as the update -- a per-tensor, per-step print-out showed it (round 5): <= 5e-5 after step 1, 3e-4 after step 2 in the tensors
         # behind a flipped branch, 2-5e-3 after step 3)
         em, ev = rel_l2(mm, o.flatten(m, cfg)), rel_l2(vv, o.flatten(v, cfg))
         print(f"un-aligned three-step moments: first {em:.2e}, second {ev:.2e}")

@@ -17,7 +17,7 @@ for H, W in ((36, 64), (64, 64)):
     tr = Translator(H, W, featsize=100, max_batch=1000, variant="real")
     tr.init_params(0)
     gc.freeze()        # a latency-critical caller's idiom: CPython's full collection (35-56 ms with torch imported) otherwise lands in one of the
-                       # timed calls -- profiles/round5_c_reward_latency.txt, tools/outlier_hunt2.py
+                       # timed calls -- profiles/round5_c_reward_latency.txt
     for B in (256, 1000):
         fr = [rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8) for _ in range(3)]
         f32 = [(x.astype(np.float32) / 127.5 - 1) for x in fr]
