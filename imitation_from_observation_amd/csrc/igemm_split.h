@@ -18,7 +18,17 @@
 
 namespace ctx {
 
+// Measurement builds (never the shipped library; VERDICT r5 item 8, profiles/round6_e_fp16_split_errors.txt):
+//   make EXTRA="-DCTX_SPLIT_TERMS=n"   n = 3 (default): a_lo b_hi + a_hi b_lo + a_hi b_hi;  2: (a_hi + a_lo) b_hi;  1: a_hi b_hi
+//   make EXTRA="-DCTX_SPLIT_F16=k"     the two terms of an operand are fp16 (11-bit significand, three bits more than bf16, same MFMA rate:
+//                                      v_mfma_f32_32x32x16_f16) of x * 2^k; the power-of-two operand scale keeps gradients and the lo terms
+//                                      above fp16's subnormals (|x| 2^k < 65504 must hold) and leaves the accumulators as 2^-2k
+#ifndef CTX_SPLIT_TERMS
+#define CTX_SPLIT_TERMS 3
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -27,6 +37,17 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
 #ifdef CTX_ABL_SPLIT_NOCVT      // timing ablation only (WRONG numbers): the staging cost of operands that arrive pre-split -- same bytes, no conversion
     hi = __float_as_uint(x0); lo = __float_as_uint(x1);
     return;
+#endif
+#ifdef CTX_SPLIT_F16
+    {
+        const float sc = (float)(1 << CTX_SPLIT_F16);
+        const f32x2 v = {x0 * sc, x1 * sc};
+        const f16x2 hv = __builtin_convertvector(v, f16x2);
+        hi = __builtin_bit_cast(uint32_t, hv);
+        const f32x2 r = {v.x - (float)hv.x, v.y - (float)hv.y};
+        lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+        return;
+    }
 #endif
     const f32x2 v = {x0, x1};
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
@@ -103,7 +124,11 @@ struct SFetch {
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+#ifdef CTX_SPLIT_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 
 template <class LA, class LB, int MI, int NI, int WM, int WN>
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
     using TB = STile<LB::KM, TN, NT>;
     constexpr int NA = TA::NPASS, NB = TB::NPASS, NLS = NA + NB;
     constexpr int STAGE = TA::FLOATS + TB::FLOATS;
-    constexpr int NGAP = 6;                            // MFMA groups per chunk: 2 k-steps x 3 terms
+    constexpr int NT_ = CTX_SPLIT_TERMS, NGAP = 2 * NT_;    // MFMA groups per chunk: 2 k-steps x 3 terms
     constexpr bool TWO_SETS = MI * NI <= 4;
     constexpr int PER = TWO_SETS ? (NLS + NGAP - 1) / NGAP : (NLS + NGAP / 2 - 1) / (NGAP / 2);   // loads (stores) per gap
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_u[];
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
             }
 #pragma unroll
             for (int g = 0; g < NGAP; ++g) {
-                const int ks = g / 3, term = g % 3;
+                const int ks = g / NT_, term = NT_ == 3 ? g % 3 : NT_ == 2 ? (g % 2 ? 2 : 0) : 2;     // 0: a_lo b_hi   1: a_hi b_lo   2: a_hi b_hi
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -246,6 +271,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_split_kernel(const LA la, 
         }
     }
 
+#ifdef CTX_SPLIT_F16
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= 1.0f / (float)(1ll << (2 * CTX_SPLIT_F16));
+#endif
     // position-major launches (rowmode 4 / 5): the destination pixel is LINEAR in the row (= image) index; the
     // block-uniform part is resolved once here, outside the unrolled loops
     const RowMap rmap = epi_rowmap(ep, prob);
