@@ -138,7 +138,14 @@ const char* ctx_last_error(const ctx_handle* h);
  *   trace_launch 0   one stderr line per distinct implicit-GEMM launch shape
  *   adam_prio    2   HIP priority of the early-Adam stream (1 low: its own hardware queue; 0 normal; -1 high; 2 = low for exact-f32 handles,
  *                    normal for split-bf16 ones, reads back resolved)  [fixed at create]
- * Results never depend on a switch beyond f32 summation order.  Not options: CTX_DEBUG_POISON=1 (debugging aid: every device
+ * Results never depend on a switch beyond f32 summation order -- tested value by value (tests/test_gpu_options.py, against the default
+ * switches on the bench's launch shapes; the defaults themselves are what every oracle suite runs):
+ *   ContextSkipNew 64x64 B = 256:  overlap 0 | posmajor 0 | xcd_swizzle 0 1 2 3 4 5 6 | balance 0 1 2 3 4 5 8 13 | wconvt 0 1 3 5 7 15 23 29 |
+ *                                  direct3 0 1 3 5 7 9 15 23 | early_adam 0 | adam_prio -1 0 1;  graph_lanes 0 1 and early_adam 0 1 also in
+ *                                  tests/test_gpu_parity.py against the oracle
+ *   ContextAEReal 36x64 B = 64:    overlap 0 1 | dconv 0 1 5 7 | rchain 0 | direct3 0 15 | posmajor 0
+ * Combinations of two non-default switches are not enumerated; cnn_* (front end) and graphs 0 run in their own suites' defaults only.
+ * Not options: CTX_DEBUG_POISON=1 (debugging aid: every device
  * buffer a handle allocates is filled with 0xFF bytes -- float NaN -- so that a read of never-written memory shows on every run),
  * CTX_RCCL_LIB (path of the librccl to dlopen, read by the
  * first ctx_dp_* call of the process). */
