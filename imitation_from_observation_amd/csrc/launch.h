@@ -12,7 +12,7 @@
 namespace ctx {
 
 // A launcher that cannot run its kernel (no tile fits, ...) records the reason here instead of printing or aborting inside a shared
-// library; the C ABI entry points turn a pending message into CTX_E_DEVICE when they finish (ctxtrans.cpp: finish / HIP checks).
+// library; the C ABI entry points turn a pending message into CTX_E_DEVICE when they finish (ctx_engine.cpp: finish / HIP checks).
 void set_launch_error(const char* fmt, ...);
 bool take_launch_error(char* buf, size_t n);       // true (and the message, cleared) if one is pending on this thread
 

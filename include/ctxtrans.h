@@ -351,7 +351,7 @@ int ctx_profile_step(ctx_handle* h, const float* d_src, const float* d_ctx, cons
 
 /* ---- test hook ------------------------------------------------------------------------------- */
 /* Copies n floats of a named internal activation / gradient buffer to the host (bring-up and
- * parity tests only; names are listed in csrc/ctxtrans.cpp). */
+ * parity tests only; names are listed in csrc/ctx_abi.cpp: ctx_debug_read). */
 int ctx_debug_read(ctx_handle* h, const char* name, float* host, size_t n);
 
 /* ---- frozen conv-net front end (mode 'oursinception') --------------------------------------------

@@ -3,7 +3,7 @@
 // ranks on N GPUs would.  The build's gpurun boxes have one GPU; real RCCL refuses two ranks on one device, so without this
 // the two-bucket / second-stream schedule of ctx_dp_train_step would first execute with N > 1 on the driver's 8-GPU node.
 //
-// Loaded through CTX_RCCL_LIB (ctxtrans.cpp: rccl_load), it exports the eight nccl* symbols the library binds.  Semantics kept:
+// Loaded through CTX_RCCL_LIB (ctx_dp.cpp: rccl_load), it exports the eight nccl* symbols the library binds.  Semantics kept:
 // collectives are ASYNCHRONOUS and STREAM-ORDERED (device->pinned copy, a host function on the stream that meets the other
 // ranks in a POSIX shared-memory segment, pinned->device copy); every rank sums the shards in rank order 0, 1, ..., so all
 // replicas receive bit-identical results (what a ring all-reduce also guarantees).  Every wait is bounded (30 s, FAKE_RCCL_TIMEOUT_S): a rank that

@@ -327,7 +327,7 @@ def test_real_inference_follows_writes_through_ctx_dev_params(T):
 
 def test_real_reward_calls_between_training_steps(T):
     """A loop that alternates training steps with the reward hook's fetches: every fetch follows the step before it (graphs captured
-    right after a step hold their own pack nodes and are replayed, not dropped -- ctxtrans.cpp: forward_inference)."""
+    right after a step hold their own pack nodes and are replayed, not dropped -- ctx_engine.cpp: forward_inference)."""
     H, W, B = 36, 64, 5
     cfg, p, fr = make(H, W, B, seed=9)
     src, ctx, tgt = (o.preprocess_u8(x) for x in fr)
