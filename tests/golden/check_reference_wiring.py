@@ -42,16 +42,24 @@ def reference_root():
 def load_reference_module(root):
     """gym/envs/mujoco/arm_shaping.py as a stand-alone module (the `gym` package itself would pull mujoco_py); must be called inside
     tf_standin.install() -- the module binds `tf` at import (arm_shaping.py:3,10; nets/inception_v3.py:21,25)."""
-    if root not in sys.path:
-        sys.path.insert(0, root)                                    # `from nets import inception_v3`, arm_shaping.py:8
+    # the reference root goes on sys.path only while its module is executed (`from nets import inception_v3`, arm_shaping.py:8) and comes
+    # off again: it holds top-level packages (`tests`, `scripts`, ...) that must not shadow this repository's in later imports -- or in
+    # the spawn()ed children of later tests, which inherit sys.path
     for m in [k for k in sys.modules if k == "nets" or k.startswith("nets.")]:
         del sys.modules[m]                                          # they hold the `tf` of an earlier install
     spec = importlib.util.spec_from_file_location("ref_arm_shaping", os.path.join(root, "gym", "envs", "mujoco", "arm_shaping.py"))
     mod = importlib.util.module_from_spec(spec)
     import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")                             # scipy.misc deprecation
-        spec.loader.exec_module(mod)
+    saved = list(sys.path)
+    sys.path.insert(0, root)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                         # scipy.misc deprecation
+            spec.loader.exec_module(mod)
+    finally:
+        sys.path[:] = saved
+        for m in [k for k in sys.modules if k == "nets" or k.startswith("nets.")]:
+            del sys.modules[m]
     return mod
 
 
