@@ -90,19 +90,34 @@ class _State:
         self.dropout_masks = None     # iterator of numpy arrays (mask / keep_prob), consumed in call order
         self.dropout_calls = 0
         self.get_variable_calls = []  # (name, created?) in call order
+        self.lenient = None           # tuple of name prefixes whose unknown variables are created as zeros (sub-graphs outside the path)
+        self.extra_vars = []          # ... and recorded here
+        self.arg_scopes = [{}]        # slim.arg_scope stack: {function name: default kwargs}
 
 
 _S = None
 
 
 class _Scope:
-    def __init__(self, name):
-        self.name = name
+    """tf.variable_scope(name_or_scope, default_name=None, values=None, reuse=None).  A scope OBJECT captured by `with ... as sc` and passed
+    back in re-enters the SAME absolute name (TF1: nets/inception_v3.py:478-483 hands its scope to inception_v3_base), a string nests."""
+
+    def __init__(self, name_or_scope, default_name=None, reuse=None):
+        self.arg, self.default_name, self.reuse_kw = name_or_scope, default_name, reuse
+        self.full = None
         self.entry = None
 
     def __enter__(self):
+        parent_full = _S.stack[-1][0] if _S.stack else ""
         inherited = bool(_S.stack and _S.stack[-1][1])
-        self.entry = [self.name, inherited]
+        if isinstance(self.arg, _Scope):
+            full = self.arg.full                                  # absolute
+        else:
+            name = self.arg if self.arg is not None else self.default_name
+            assert isinstance(name, str), "variable_scope needs a name, a scope object or a default_name"
+            full = parent_full + "/" + name if parent_full else name
+        self.full = full
+        self.entry = [full, inherited or bool(self.reuse_kw)]
         _S.stack.append(self.entry)
         return self
 
@@ -114,13 +129,13 @@ class _Scope:
         self.entry[1] = True
 
 
-def variable_scope(name_or_scope, *a, **k):
-    assert isinstance(name_or_scope, str), "the live classes only open scopes by name"
-    return _Scope(name_or_scope)
+def variable_scope(name_or_scope, default_name=None, values=None, reuse=None):
+    return _Scope(name_or_scope, default_name, reuse)
 
 
-def get_variable(name, shape=None, dtype=None, initializer=None):
-    full = "/".join([s[0] for s in _S.stack] + [name])
+def get_variable(name, shape=None, dtype=None, initializer=None, **kw):
+    prefix = _S.stack[-1][0] if _S.stack else ""
+    full = prefix + "/" + name if prefix else name
     reuse = bool(_S.stack and _S.stack[-1][1])
     shape = [int(d) for d in shape]
     if full in _S.vars:
@@ -133,6 +148,11 @@ def get_variable(name, shape=None, dtype=None, initializer=None):
     if reuse:
         raise ValueError(f"Variable {full} does not exist, or was not created with tf.get_variable().")
     if full not in _S.values:
+        if _S.lenient is not None and full.startswith(_S.lenient):  # variables of a sub-graph outside the path under check: zeros, recorded
+            v = torch.zeros(shape, dtype=DT)
+            _S.vars[full] = v
+            _S.extra_vars.append((full, tuple(shape)))
+            return Tensor(v)
         raise KeyError(f"the reference creates variable {full} {shape}, which the oracle's inventory does not hold")
     val = _S.values[full]
     assert list(val.shape) == shape, f"{full}: the reference asks for shape {shape}, the oracle holds {list(val.shape)}"
@@ -161,9 +181,11 @@ def _conv2d_same_nchw(x, w_oihw, sh, sw):
 
 
 def conv2d(input, filter, strides, padding):
-    assert padding == "SAME" and strides[0] == 1 and strides[3] == 1
+    assert padding in ("SAME", "VALID") and strides[0] == 1 and strides[3] == 1
     x = _raw(input).permute(0, 3, 1, 2)                      # NHWC -> NCHW
     w = _raw(filter).permute(3, 2, 0, 1)                     # HWIO -> OIHW
+    if padding == "VALID":
+        return Tensor(F.conv2d(x, w, stride=(strides[1], strides[2])).permute(0, 2, 3, 1))
     return Tensor(_conv2d_same_nchw(x, w, strides[1], strides[2]).permute(0, 2, 3, 1))
 
 
@@ -198,7 +220,9 @@ def matmul(a, b):
     return Tensor(_raw(a) @ _raw(b))
 
 
-def concat(values, axis):
+def concat(values=None, axis=None, **kw):
+    if isinstance(values, int):                              # (the pre-1.0 positional order concat(axis, values) is not used by the files under check)
+        values, axis = axis, values
     return Tensor(torch.cat([_raw(v) for v in values], dim=axis))
 
 
@@ -216,7 +240,7 @@ def l2_loss(t):
     return Tensor((_raw(t) ** 2).sum() / 2)
 
 
-def dropout(x, keep_prob):
+def nn_dropout(x, keep_prob):
     _S.dropout_calls += 1
     if keep_prob == 1.0:
         return x                                             # TF returns x itself for keep_prob == 1
@@ -229,6 +253,137 @@ def dropout(x, keep_prob):
 def placeholder(value):
     """Not tf.placeholder's signature: the check feeds the value directly (eager)."""
     return Tensor(torch.tensor(value, dtype=DT))
+
+
+# --------------------------------------------------------------------------------------------------------- tf.contrib.slim
+# The handful of slim layers nets/inception_v3.py and nets/inception_utils.py use, with slim's arg_scope mechanics (defaults per function,
+# nested scopes merge, a captured scope can be re-applied).  Same caveat as above: this file's own statement of slim's published
+# behaviour (conv2d = conv -> normalizer_fn OR biases -> activation_fn; batch_norm in inference mode = (x - moving_mean) /
+# sqrt(moving_variance + epsilon) [* gamma] + beta with variables beta / gamma / moving_mean / moving_variance under <scope>/BatchNorm;
+# SAME average pooling divides by the number of taps inside the image), not slim.
+def _two(v):
+    return [int(v), int(v)] if isinstance(v, int) else [int(v[0]), int(v[1])]
+
+
+def _scoped(key):
+    def deco(fn):
+        def wrapper(*a, **k):
+            merged = dict(_S.arg_scopes[-1].get(key, {}))
+            merged.update(k)
+            return fn(*a, **merged)
+        wrapper.__name__ = key
+        wrapper._slim_key = key
+        return wrapper
+    return deco
+
+
+@contextlib.contextmanager
+def arg_scope(list_ops_or_scope, **kwargs):
+    cur = {k: dict(v) for k, v in _S.arg_scopes[-1].items()}
+    if isinstance(list_ops_or_scope, dict):
+        assert not kwargs
+        for k, v in list_ops_or_scope.items():
+            cur.setdefault(k, {}).update(v)
+    else:
+        for op in list_ops_or_scope:
+            cur.setdefault(op._slim_key, {}).update(kwargs)
+    _S.arg_scopes.append(cur)
+    try:
+        yield cur
+    finally:
+        _S.arg_scopes.pop()
+
+
+def relu(x):
+    return Tensor(torch.relu(_raw(x)))
+
+
+@_scoped("batch_norm")
+def batch_norm(inputs, decay=0.999, center=True, scale=False, epsilon=0.001, is_training=True, updates_collections=None, scope=None, **kw):
+    assert not is_training, "the path under check runs the front end with is_training=False (rllab/sampler/base.py:122-127)"
+    c = int(_raw(inputs).shape[-1])
+    with variable_scope(scope, "BatchNorm"):
+        beta = _raw(get_variable("beta", [c])) if center else 0.0
+        gamma = _raw(get_variable("gamma", [c])) if scale else 1.0
+        mean = _raw(get_variable("moving_mean", [c]))
+        var = _raw(get_variable("moving_variance", [c]))
+    return Tensor((_raw(inputs) - mean) / torch.sqrt(var + epsilon) * gamma + beta)
+
+
+@_scoped("conv2d")
+def slim_conv2d(inputs, num_outputs, kernel_size, stride=1, padding="SAME", activation_fn=relu, normalizer_fn=None, normalizer_params=None,
+                weights_initializer=None, weights_regularizer=None, biases_initializer=None, scope=None, **kw):
+    kh, kw_ = _two(kernel_size)
+    sh, sw = _two(stride)
+    cin = int(_raw(inputs).shape[-1])
+    with variable_scope(scope, "Conv"):
+        w = get_variable("weights", [kh, kw_, cin, int(num_outputs)])
+        out = conv2d(inputs, w, [1, sh, sw, 1], padding)
+        if normalizer_fn is not None:
+            out = normalizer_fn(out, **(normalizer_params or {}))
+        else:
+            out = Tensor(_raw(out) + _raw(get_variable("biases", [int(num_outputs)])))
+        if activation_fn is not None:
+            out = activation_fn(out)
+    return out
+
+
+
+def _pool_pads(n, k, s, padding):
+    if padding == "VALID":
+        return 0, 0
+    return _same_pads(n, k, s)
+
+
+@_scoped("max_pool2d")
+def max_pool2d(inputs, kernel_size, stride=2, padding="VALID", scope=None, **kw):
+    kh, kw_ = _two(kernel_size)
+    sh, sw = _two(stride)
+    x = _raw(inputs).permute(0, 3, 1, 2)
+    pt, pb = _pool_pads(x.shape[2], kh, sh, padding)
+    pl, pr = _pool_pads(x.shape[3], kw_, sw, padding)
+    x = F.pad(x, (pl, pr, pt, pb), value=float("-inf"))
+    return Tensor(F.max_pool2d(x, (kh, kw_), stride=(sh, sw)).permute(0, 2, 3, 1))
+
+
+@_scoped("avg_pool2d")
+def avg_pool2d(inputs, kernel_size, stride=2, padding="VALID", scope=None, **kw):
+    kh, kw_ = _two(kernel_size)
+    sh, sw = _two(stride)
+    x = _raw(inputs).permute(0, 3, 1, 2)
+    pt, pb = _pool_pads(x.shape[2], kh, sh, padding)
+    pl, pr = _pool_pads(x.shape[3], kw_, sw, padding)
+    ones = F.pad(torch.ones((1, 1) + tuple(x.shape[2:]), dtype=DT), (pl, pr, pt, pb))
+    xs = F.avg_pool2d(F.pad(x, (pl, pr, pt, pb)), (kh, kw_), stride=(sh, sw)) * (kh * kw_)
+    cnt = F.avg_pool2d(ones, (kh, kw_), stride=(sh, sw)) * (kh * kw_)           # taps inside the image
+    return Tensor((xs / cnt).permute(0, 2, 3, 1))
+
+
+@_scoped("dropout")
+def dropout(inputs, keep_prob=0.5, is_training=True, scope=None, **kw):
+    assert not is_training
+    return inputs
+
+
+def softmax(logits, scope=None):
+    return Tensor(torch.softmax(_raw(logits), dim=-1))
+
+
+def squeeze(x, axis=None, name=None):
+    t = _raw(x)
+    for a in sorted(axis or [], reverse=True):
+        t = t.squeeze(a)
+    return Tensor(t)
+
+
+def _slim_namespace():
+    ns = types.SimpleNamespace(arg_scope=arg_scope, conv2d=slim_conv2d, batch_norm=batch_norm, max_pool2d=max_pool2d, avg_pool2d=avg_pool2d,
+                               dropout=dropout, softmax=softmax, l2_regularizer=lambda *a, **k: None,
+                               variance_scaling_initializer=lambda *a, **k: None, ops=types.SimpleNamespace())
+    def _fc(*a, **k):
+        raise NotImplementedError("slim.fully_connected is outside the path under check")
+    ns.fully_connected = _scoped("fully_connected")(_fc)
+    return ns
 
 
 # ------------------------------------------------------------------------------------------------------------- install
@@ -250,8 +405,10 @@ def _module(values):
     tf.truncated_normal_initializer = tf.random_normal_initializer = tf.constant_initializer = _initializer
     tf.reshape, tf.maximum, tf.matmul, tf.concat, tf.reduce_mean = reshape, maximum, matmul, concat, reduce_mean
     tf.nn = types.SimpleNamespace(conv2d=conv2d, conv2d_transpose=conv2d_transpose, bias_add=bias_add, moments=moments,
-                                  l2_loss=l2_loss, dropout=dropout)
-    tf.contrib = types.SimpleNamespace(slim=_Inert(), layers=_Inert())
+                                  l2_loss=l2_loss, dropout=nn_dropout, relu=relu)
+    tf.squeeze = squeeze
+    tf.GraphKeys = types.SimpleNamespace(UPDATE_OPS="update_ops")
+    tf.contrib = types.SimpleNamespace(slim=_slim_namespace(), layers=_Inert())
     tf.gfile = types.ModuleType("tensorflow.gfile")
     return tf
 

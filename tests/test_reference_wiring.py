@@ -11,6 +11,7 @@ import pytest
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 if GOLD not in sys.path:
     sys.path.insert(0, GOLD)
+import check_reference_inception as cri  # noqa: E402
 import check_reference_wiring as crw  # noqa: E402
 import tf_standin  # noqa: E402
 
@@ -26,6 +27,18 @@ def test_reference_build_equals_oracle(name):
     # sharing: every variable is created once; the second / third pass through a scope only re-uses
     assert len(created) == len(set(created))
     assert {n for n, new in log if not new} <= set(created)
+
+
+@pytest.mark.parametrize("name", list(cri.CASES))
+def test_reference_inception_v3_equals_oracle(name):
+    """nets/inception_v3.py `inception_v3(images, num_classes=1001, is_training=False)` under `inception_v3_arg_scope()` -- the front end as
+    rllab/sampler/base.py:121-127 builds it -- on the slim stand-in: all 18 end points to Mixed_7c equal oracle/inception_oracle.py, the 376
+    variables it creates up to there are the oracle's inventory (names and shapes), the rest are the two classifier heads the path never fetches."""
+    rows, worst, created, extra = cri.CASES[name]()
+    bad = [(n, d) for n, _, d in rows if not d <= cri.BAR]
+    assert not bad, bad
+    assert len(rows) == 18 and len(created) == 376 and len(set(created)) == 376
+    assert all(n.startswith(("InceptionV3/AuxLogits/", "InceptionV3/Logits/")) for n, _ in extra) and len(extra) == 12
 
 
 def test_the_check_sees_a_wiring_error(monkeypatch):
