@@ -12,6 +12,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 if GOLD not in sys.path:
     sys.path.insert(0, GOLD)
 import check_reference_inception as cri  # noqa: E402
+import check_reference_reward as crr  # noqa: E402
 import check_reference_wiring as crw  # noqa: E402
 import tf_standin  # noqa: E402
 
@@ -39,6 +40,16 @@ def test_reference_inception_v3_equals_oracle(name):
     assert not bad, bad
     assert len(rows) == 18 and len(created) == 376 and len(set(created)) == 376
     assert all(n.startswith(("InceptionV3/AuxLogits/", "InceptionV3/Logits/")) for n, _ in extra) and len(extra) == 12
+
+
+@pytest.mark.parametrize("name", list(crr.CASES))
+def test_reference_process_samples_equals_the_reward_hook(name):
+    """The reference's own `BaseSampler.process_samples` (rllab/sampler/base.py:165-257, 'ours' branch: demo cache, per-path cost, the
+    reward update, and the advantage / return code behind it) executed on stand-in packages with a session answered by the oracle, against
+    reward.TranslatorReward on the same paths: `path["rewards"]` agree to 1e-6 (names 'strike' nvp 2, 'sweep' with its frame skip of 2, 'reach')."""
+    worst, calls = crr.CASES[name]()
+    assert worst <= crr.BAR, worst
+    assert ("TRANSLATED_Z", "OUT") in calls and ("INPUT_Z", "IMAGE_TRANS") in calls
 
 
 def test_the_check_sees_a_wiring_error(monkeypatch):
