@@ -164,18 +164,13 @@ __global__ __launch_bounds__((NWM + NWG) * 64) void convt3m_kernel(const Ct3m A)
             const int done = (st + 1) * SP < A.npix ? (st + 1) * SP : A.npix;
             const int Ra = done == A.npix ? A.hin : done / A.win;          // complete input rows
             const int Rp = st == 0 ? 0 : (st * SP) / A.win;                // ... after the previous step
-            int y0, y1;
-            if constexpr (S == 2) {                            // out row 2 i + py needs input rows <= i + py
-                y0 = st == 0 ? 0 : (Rp >= 1 ? 2 * (Rp - 1) : 0);
-                y1 = Ra == A.hin ? hout : (Ra >= 1 ? 2 * (Ra - 1) : 0);
-            } else {                                           // out row y needs input rows <= y + 2
-                y0 = st == 0 ? 0 : (Rp >= 2 ? Rp - 2 : 0);
-                y1 = Ra == A.hin ? hout : (Ra >= 2 ? Ra - 2 : 0);
-            }
+            // stride 2: out row 2 i + py needs input rows <= i + py
+            const int y0 = st == 0 ? 0 : (Rp >= 1 ? 2 * (Rp - 1) : 0);
+            const int y1 = Ra == A.hin ? hout : (Ra >= 1 ? 2 * (Ra - 1) : 0);
             for (int yb = y0; yb < y1; yb += RPP) {            // (uniform: the ring slot of the pass's first input row comes from the scalar unit)
                 const int y = yb + rofs;
                 if (rofs >= RPP || y >= y1) continue;
-                if constexpr (S == 2) {
+                {
                     // out(2 i + py, 2 j + px): py 0 <- (i, ky 1), (i - 1, ky 3);  py 1 <- (i + 1, ky 0), (i, ky 2), (i - 1, ky 4)
                     //                          px 0 <- (j, kx 1), (j - 1, kx 3);  px 1 <- (j + 1, kx 0), (j, kx 2), (j - 1, kx 4)
                     // -- over the two pixels of a thread every (row term, kx) is used exactly once: 5 taps x 3 channels per row term
@@ -211,40 +206,57 @@ __global__ __launch_bounds__((NWM + NWG) * 64) void convt3m_kernel(const Ct3m A)
                     }
                     float2* o = reinterpret_cast<float2*>(A.out + (((int64_t)img * hout + y) * wout + 2 * j) * 3);
                     o[0] = float2{e0, e1}; o[1] = float2{e2, o0}; o[2] = float2{o1, o2};
-                } else {
-                    // out(y, x) = sum_{ky, kx} P[(y + 2 - ky, x + 2 - kx)][(ky, kx, c)]
-                    const int rbase = (yb * A.win) % A.RP;
-                    float o0 = bias0, o1 = bias1, o2 = bias2;
+                }
+            }
+        };
+        // stride 1: out(y, x) = sum_{ky, kx} P[(y + 2 - ky, x + 2 - kx)][(ky, kx, c)] -- 25 taps per pixel and only 16 NWM pixels per step, so
+        // each pixel is shared by the two lanes l, l + 32 of a wave (filter rows 0..2 | 3..4) and the halves meet through one shuffle
+        auto gather1 = [&](int img, int st) {
+            const int done = (st + 1) * SP < A.npix ? (st + 1) * SP : A.npix;
+            const int Ra = done == A.npix ? A.hin : done / A.win;
+            const int Rp = st == 0 ? 0 : (st * SP) / A.win;
+            const int y0 = st == 0 ? 0 : (Rp >= 2 ? Rp - 2 : 0);
+            const int y1 = Ra == A.hin ? hout : (Ra >= 2 ? Ra - 2 : 0);
+            const int half = (gt >> 5) & 1, it = (gt >> 6) * 32 + (gt & 31), PPP = NG / 2;      // pixels per pass
+            const int total = (y1 - y0) * A.win;
+            for (int base = 0; base < total; base += PPP) {
+                const int e = base + it, yy = e / A.win, jx = e - yy * A.win, y = y0 + yy;
+                const bool live = e < total;
+                const int yc = live ? y : y0;
+                const int rbase = (y0 * A.win) % A.RP;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll 1
-                    for (int ky = 0; ky < 5; ++ky) {
-                        const int ii = y + 2 - ky;
-                        const bool rok = ii >= 0 && ii < A.hin;
-                        int rs = rbase + (ii - yb) * A.win;
-                        rs = rs < 0 ? rs + A.RP : rs;
-                        while (rs >= A.RP) rs -= A.RP;
-                        int off[5];
+                for (int ky = half ? 3 : 0; ky < (half ? 5 : 3); ++ky) {
+                    const int ii = yc + 2 - ky;
+                    const bool rok = live && ii >= 0 && ii < A.hin;
+                    int rs = rbase + (ii - y0) * A.win;
+                    rs = rs < 0 ? rs + A.RP : rs;
+                    while (rs >= A.RP) rs -= A.RP;
+                    int off[5];
 #pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) {
-                            const int jj = j + 2 - kx;
-                            int slot = rs + jj;
-                            slot = slot >= A.RP ? slot - A.RP : slot;
-                            off[kx] = rok && jj >= 0 && jj < A.win ? slot * M3_PST + ky * 15 + kx * 3 : ZS;
-                        }
-                        float v[5][3];
-#pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) { v[kx][0] = P[off[kx]]; v[kx][1] = P[off[kx] + 1]; v[kx][2] = P[off[kx] + 2]; }
-#pragma unroll
-                        for (int kx = 0; kx < 5; ++kx) { o0 += v[kx][0]; o1 += v[kx][1]; o2 += v[kx][2]; }
+                    for (int kx = 0; kx < 5; ++kx) {
+                        const int jj = jx + 2 - kx;
+                        int slot = rs + jj;
+                        slot = slot >= A.RP ? slot - A.RP : slot;
+                        off[kx] = rok && jj >= 0 && jj < A.win ? slot * M3_PST + ky * 15 + kx * 3 : ZS;
                     }
-                    float* o = A.out + (((int64_t)img * hout + y) * wout + j) * 3;
-                    o[0] = o0; o[1] = o1; o[2] = o2;
+                    float v[5][3];
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) { v[kx][0] = P[off[kx]]; v[kx][1] = P[off[kx] + 1]; v[kx][2] = P[off[kx] + 2]; }
+#pragma unroll
+                    for (int kx = 0; kx < 5; ++kx) { s0 += v[kx][0]; s1 += v[kx][1]; s2 += v[kx][2]; }
+                }
+                const float t0 = __shfl_xor(s0, 32), t1 = __shfl_xor(s1, 32), t2 = __shfl_xor(s2, 32);
+                if (live && half == 0) {
+                    float* o = A.out + (((int64_t)img * hout + y) * wout + jx) * 3;
+                    o[0] = bias0 + s0 + t0; o[1] = bias1 + s1 + t1; o[2] = bias2 + s2 + t2;
                 }
             }
         };
         int img = blockIdx.x, st = 0, pimg = -1, pst = 0;
         while (img < A.nimg) {
             M3_STAMP(0);
-            if (pimg >= 0) gather(pimg, pst);
+            if (pimg >= 0) { if constexpr (S == 2) gather(pimg, pst); else gather1(pimg, pst); }
             M3_STAMP(1);
             __syncthreads();                                   // B1
             M3_STAMP(2);
@@ -254,7 +266,7 @@ __global__ __launch_bounds__((NWM + NWG) * 64) void convt3m_kernel(const Ct3m A)
             pimg = img; pst = st;
             if (++st == A.steps) { st = 0; img += gridDim.x; }
         }
-        if (pimg >= 0) gather(pimg, pst);
+        if (pimg >= 0) { if constexpr (S == 2) gather(pimg, pst); else gather1(pimg, pst); }
     }
 }
 
