@@ -15,6 +15,5 @@ cp $O/real_layers.txt ${P}_context_ae_real_layers.txt
 cp $O/config4.txt ${P}_config4_inception_end_to_end.txt
 cp $O/frontend_layers.txt ${P}_inception_frontend_layers.txt
 grep -E "passed|failed" $O/pytest_gpu.txt > ${P}_pytest_gpu.txt
-[ -f $O/reward_trace/last_call_kernels.txt ] && cp $O/reward_trace/last_call_kernels.txt ${P}_reward_trace.txt
 ls $O/pmc_wconvt_kernel/*.txt 2>/dev/null | head -1 | xargs -I{} cp {} ${P}_pmc_wconvt.txt
 ls -la ${P}_* | awk '{print $5, $9}'
