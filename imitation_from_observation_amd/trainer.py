@@ -189,7 +189,8 @@ class ModelTrainer:
             raise ValueError(f"vdata must be [T >= {self.nlen}, N, {self.idims[0]}, {self.idims[1]}, 3], got {vdata.shape}")
         B, nlen = self.batch_size, self.nlen
         log = self.log if rank == 0 else (lambda s: None)          # one log, one set of files: rank 0's
-        log(str(vdata.shape))
+        if not (self.vdata is None and self.videos is not None):
+            log(str(vdata.shape))                                  # (:96 -- build_vdata logs it on the `videos=` path)
         Bl, j0 = B // world, rank * (B // world)                   # this rank's rows of the global batch
         n = vdata.shape[1]
         ntrain = self.ntrain

@@ -1,0 +1,611 @@
+"""Runs the REFERENCE'S OWN training script -- `ModelTrainer.train()` of scripts/train_script.py:28-204: the video loop (:59-96: shuffle, 51-frame
+rule, frame selection by nskip, `transform`, the black-frame drop, the `nvideos` cap, the saved `vdata_strike<itr>.npy`), the train / validation
+split (:144-152), the batch assembly (:153-159, :169-174, :186-190), the four `sess.run` sites with their fetch lists and feeds (:163-167, :176,
+:191-192), the logging / validation / checkpoint / clip / tabular cadence (:160-203) -- loaded from REFERENCE_ROOT at run time, and compares what it
+DOES with this repository's trainer (imitation_from_observation_amd.trainer.ModelTrainer over demo_pipeline.build_vdata) on the same synthetic
+videos and the same np.random seed:
+
+    * the saved demo tensor (file name and bytes) and `vdata_train.npy`;
+    * every batch that reaches a `sess.run`, in order, with its kind (train / train + log / validation / clip), bit for bit, and the learning rate fed;
+    * the optimiser's construction (AdamOptimizer(learning_rate) with TF's defaults, minimize(loss, var_list = the "contextmodel" collection));
+    * the log lines of the training phase, `validloss.npy`, the checkpoint paths, the clip frames handed to the GIF writer, the tabular rows;
+    * where np.random stands afterwards.
+
+How it can run here: every import of the script that is not its subject is a stand-in -- `tensorflow` is a small deferred graph (placeholders, the
+four reductions of the `nn_err` expression :148, a Session that evaluates fetches on the fed batch), `arm_shaping.ContextSkipNew` a model whose
+fetches are answered by the float64 oracle (the model itself is pinned by check_reference_wiring.py), `imageio.get_reader` serves the synthetic
+videos, `scipy.misc.imresize` (removed from scipy; its published body: PIL `Image.resize(..., BILINEAR)` on uint8 data) is restated over Pillow,
+`rllab.misc.logger` records.  ONE repair is made to the script, in memory: its non-Inception branch reads `featreshape` in `nn_err` (:148), a local
+that only the Inception branch assigns (:112) -- as written that branch dies with UnboundLocalError before its first iteration.
+`featreshape = tfinput` is put in front of :148, the meaning the Inception branch gives the name (`featreshape[2]` = the tgt slot of what the
+model is built on).  Everything else runs as it stands.  The script's INCEPTION branch (:98-114, :135-139) needs no repair and is run as written
+too (compare_inception: uint8 frames, the preprocessing chain, inception_v3's arguments, Mixed_7c reshaped as the model's input, the restore and
+the classifier run on the bird picture, no clips).  Build container only; nothing of the reference is stored.
+
+    python tests/golden/check_reference_trainer.py
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+from imitation_from_observation_amd import trainer as our_trainer  # noqa: E402
+from oracle import ctx_oracle as o  # noqa: E402
+
+H = W = 16
+CFG = o.SkipNewConfig(H=H, W=W, df_dim=4, gf_dim=4, featsize=8)
+B, NLEN, NSKIP, NVIDEOS, NTRAIN, NITR, SAVE = 6, 3, 17, 11, 6, 45, 20        # frames 1, 18, 35 of 51; validation at 20, 40; checkpoints at 20, 40
+
+
+def reference_root():
+    return os.environ.get("REFERENCE_ROOT", "/root/reference")
+
+
+# ---------------------------------------------------------------------------------------------------------------- synthetic videos
+def make_videos(seed=5):
+    """14 decoded 'videos' (arrays [nframes, 24, 32, 3] uint8): one of 40 frames (skipped and counted, :72, :85), one whose first kept frame
+    is black (dropped, NOT counted: :76-82), one whose reader raises (counted as a failure, :88-93), more good ones than `nvideos` looks at."""
+    rng = np.random.default_rng(seed)
+    vids = []
+    for i in range(14):
+        n = 40 if i == 3 else 51
+        base = rng.integers(0, 256, (1, 6, 8, 3), dtype=np.uint8).repeat(4, 1).repeat(4, 2)
+        v = np.clip(base.astype(np.int64) + rng.integers(-20, 21, (n, 24, 32, 3)), 0, 255).astype(np.uint8)
+        if i == 7:
+            v[1] = 0
+        vids.append(v)
+    return vids, {9}                                                            # video 9: unreadable
+
+
+# ---------------------------------------------------------------------------------------------------------------- the model behind sess.run
+class OracleModel:
+    """What a fetch returns: the float64 oracle on the fed batch (ContextSkipNew 16x16, df_dim 4).  Records every batch it is handed."""
+
+    def __init__(self, seed=3):
+        self.p = o.init_params(CFG, seed, np.float64, stddev=0.05)
+        self.m = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: np.zeros_like(v) for k, v in self.p.items()}
+        self.t = 0
+        self.calls, self.saved = [], []
+
+    def train_step(self, src, ctx, tgt, lr):
+        self.calls.append(("train", float(lr), np.stack([np.asarray(x, np.float64) for x in (src, ctx, tgt)])))
+        self.t += 1
+        res, _ = o.train_step(self.p, self.m, self.v, self.t, *(np.asarray(x, np.float64) for x in (src, ctx, tgt)), lr, CFG)
+        self._last = (res["out"], np.asarray(tgt, np.float64))
+        return {k: (float(res[k]) if np.ndim(res[k]) == 0 else res[k]) for k in ("loss", "simloss", "recon1", "recon2", "out", "out2")}
+
+    def evaluate(self, src, ctx, tgt):
+        self.calls.append(("eval", None, np.stack([np.asarray(x, np.float64) for x in (src, ctx, tgt)])))
+        res, _ = o.forward(self.p, *(np.asarray(x, np.float64) for x in (src, ctx, tgt)), CFG)
+        return {k: (float(res[k]) if np.ndim(res[k]) == 0 else res[k]) for k in ("loss", "simloss", "recon1", "recon2", "out", "out2")}
+
+    def last_outputs(self, out=True, out2=False, tgt=False):
+        return self._last[0], None, self._last[1]
+
+    def save(self, path, prefix=""):
+        self.saved.append((path, prefix))
+
+
+# ---- the Inception branch's stand-ins: a fixed "front end" (8x8 average pooling, a fixed 3 -> 8 channel map) and a model on its feature maps
+_PROJ = np.random.default_rng(99).standard_normal((3, 8))
+STRIDES, KERNELS, FILTERS = [1, 2, 1, 2], [3, 3, 3, 3], [16, 16, 8, 8]
+
+
+def front_end(images):
+    """images f32 [N, 16, 16, 3] in [-1, 1] -> 'Mixed_7c' [N, 2, 2, 8]"""
+    x = np.asarray(images, np.float64)
+    return x.reshape(x.shape[0], 2, 8, 2, 8, 3).mean(axis=(2, 4)) @ _PROJ
+
+
+def preprocess_u8(u8):
+    """train_script.py:101-103: convert_image_dtype(uint8 -> float32) (TF: cast, then * 1/255), - 0.5, * 2.0"""
+    x = np.asarray(u8).astype(np.float32) * np.float32(1.0 / 255)
+    return (x - np.float32(0.5)) * np.float32(2.0)
+
+
+class FeatureModel:
+    """The model on feature maps [3, B, 2, 2, 8]: cheap closed forms (the model is not this check's subject), with a step counter so that the
+    ORDER of optimiser and evaluation runs shows in every number."""
+
+    def __init__(self):
+        self.t = 0
+        self.saved = []
+
+    def _res(self, f):
+        s = 1.0 + 0.01 * self.t
+        out, out2 = s * 0.5 * (f[0] + f[1]) + 0.1, s * 0.9 * f[2]
+        r1, r2, sim = float(((out - f[2]) ** 2).sum() / 2), float(((out2 - f[2]) ** 2).sum() / 2), float(((f[0] - f[1]) ** 2).mean())
+        return {"loss": r1 + r2 + sim, "simloss": sim, "recon1": r1, "recon2": r2, "out": out, "out2": out2}
+
+    def train_step(self, fs, fc, ft, lr):
+        assert float(lr) == 1e-4
+        self.t += 1
+        return self._res(np.stack([fs, fc, ft]))
+
+    def evaluate(self, fs, fc, ft):
+        return self._res(np.stack([fs, fc, ft]))
+
+
+class FakeInceptionTranslator:
+    """InceptionTranslator's surface (oursinception.py) as trainer.ModelTrainer drives it, on the stand-in front end and FeatureModel."""
+
+    def __init__(self):
+        self.model, self.fed, self.saved = FeatureModel(), [], []
+        self.tr = self                                                          # trainer: core = getattr(tr, "tr", tr)
+
+    def _feats(self, kind, src, ctx, tgt):
+        u8 = np.stack([np.asarray(x) for x in (src, ctx, tgt)])
+        assert u8.dtype == np.uint8
+        self.fed.append((kind, u8.copy()))
+        return front_end(preprocess_u8(u8).reshape((-1,) + u8.shape[2:])).reshape(3, u8.shape[1], 2, 2, 8)
+
+    def train_step_u8(self, src, ctx, tgt, lr=1e-4):
+        f = self._feats("train", src, ctx, tgt)
+        res = self.model.train_step(f[0], f[1], f[2], lr)
+        self._last = (res["out"], f[2])
+        return res
+
+    def evaluate_u8(self, src, ctx, tgt):
+        f = self._feats("eval", src, ctx, tgt)
+        res = dict(self.model.evaluate(f[0], f[1], f[2]))
+        res["tgt"] = f[2]
+        return res
+
+    def last_outputs(self, out=True, out2=False, tgt=False):
+        return self._last[0], None, self._last[1]
+
+    def save(self, path, prefix=""):
+        self.saved.append((path, prefix))
+
+
+# ---------------------------------------------------------------------------------------------------------------- a deferred-graph `tensorflow`
+class Node:
+    def __init__(self, fn, tag=None):
+        self.fn, self.tag = fn, tag
+
+    def __getitem__(self, k):
+        return Node(lambda e: self.fn(e)[k])
+
+    def __sub__(self, other):
+        return Node(lambda e: self.fn(e) - val(other, e))
+
+    def __rsub__(self, other):
+        return Node(lambda e: val(other, e) - self.fn(e))
+
+    def __pow__(self, k):
+        return Node(lambda e: self.fn(e) ** k)
+
+    def get_shape(self):
+        raise AssertionError("not on the non-Inception path")
+
+
+def val(x, e):
+    return x.fn(e) if isinstance(x, Node) else x
+
+
+class Placeholder(Node):
+    def __init__(self, dtype, shape=None, name=None):
+        super().__init__(lambda e: np.asarray(e["feed"][self]), tag="placeholder")
+        self.dtype, self.shape, self.name = dtype, shape, name
+
+    __hash__ = object.__hash__
+
+
+def make_tf(model, record):
+    tf = types.ModuleType("tensorflow")
+    tf.float32, tf.uint8 = "float32", "uint8"
+    tf.contrib = types.SimpleNamespace(slim=types.SimpleNamespace())
+    tf.gfile = types.SimpleNamespace(Glob=lambda pat: record.glob(pat))
+    tf.placeholder = lambda dtype, shape=None, name=None: record.placeholder(Placeholder(dtype, shape, name))
+    tf.reduce_mean = lambda x, axis=None: Node(lambda e: np.mean(val(x, e), axis=axis))
+    tf.reduce_sum = lambda x, axis=None: Node(lambda e: np.sum(val(x, e), axis=axis))
+    tf.argmin = lambda x, axis=None: Node(lambda e: np.argmin(val(x, e), axis=axis))
+    tf.abs = lambda x: Node(lambda e: np.abs(val(x, e)))
+    tf.reshape = lambda tensor, shape: Node(lambda e: np.reshape(val(tensor, e), shape))
+    tf.subtract = lambda x, y: Node(lambda e: val(x, e) - np.float32(y))
+    tf.multiply = lambda x, y: Node(lambda e: val(x, e) * np.float32(y))
+
+    def convert_image_dtype(x, dtype=None):
+        assert dtype == "float32"
+        return Node(lambda e: (lambda v: (record.converted.append(v.dtype), v.astype(np.float32) * np.float32(1.0 / 255))[1])(val(x, e)))
+    tf.image = types.SimpleNamespace(convert_image_dtype=convert_image_dtype)
+
+    class _ArgScope:
+        def __init__(self, *a, **k):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    tf.contrib.slim.arg_scope = _ArgScope
+    tf.contrib.slim.get_variables_to_restore = lambda: "variables_to_restore"
+    tf.GraphKeys = types.SimpleNamespace(TRAINABLE_VARIABLES="trainable_variables")
+    tf.get_collection = lambda key, scope=None: ("collection", key, scope)
+    tf.global_variables_initializer = lambda: Node(None, tag="init")
+
+    class _Scope:
+        def __init__(self, name):
+            record.scopes.append(name)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    tf.variable_scope = _Scope
+
+    class AdamOptimizer:
+        def __init__(self, *a, **k):
+            record.adam_args = (a, k)
+
+        def minimize(self, loss, var_list=None):
+            record.minimize = (loss, var_list)
+            return Node(None, tag="optimizer")
+
+    class Saver:
+        def __init__(self, *a, **k):
+            self.args = a
+
+        def save(self, sess, path):
+            record.saved.append(path)
+
+        def restore(self, sess, path):
+            record.restored.append((self.args, path))
+
+    class Session:
+        def run(self, fetches, feed_dict=None):
+            single = not isinstance(fetches, (list, tuple))
+            fl = [fetches] if single else list(fetches)
+            if all(f.tag == "init" for f in fl):
+                record.initialised = True
+                return None
+            image = [k for k in feed_dict if isinstance(k, Placeholder) and k.name in ("x", "image")]
+            assert len(image) == 1, "one image placeholder is fed"
+            e = {"feed": feed_dict}
+            if all(f.tag == "logits" for f in fl):                     # the classifier sanity run on the bird picture (:138)
+                record.logits_fed.append(np.asarray(feed_dict[image[0]]))
+                out = [val(f, e) for f in fl]
+                return out[0] if single else out
+            record.fed.append(np.asarray(feed_dict[image[0]]).copy())
+            batch = np.asarray(val(record.model_input, e))               # what the model was built on: the placeholder, or Mixed_7c reshaped (:113)
+            lrs = [feed_dict[k] for k in feed_dict if isinstance(k, Placeholder) and k.shape == []]
+            step = any(f.tag == "optimizer" for f in fl)
+            if step:
+                assert len(lrs) == 1, "the learning rate is fed with every optimiser run (:163, :167)"
+                res = model.train_step(batch[0], batch[1], batch[2], lrs[0])
+            else:
+                res = model.evaluate(batch[0], batch[1], batch[2])
+            record.runs.append((("train" if step else "eval"), tuple(f.tag or "expr" for f in fl)))
+            e["res"] = res
+            out = [None if f.tag == "optimizer" else val(f, e) for f in fl]
+            return out[0] if single else out
+    tf.train = types.SimpleNamespace(AdamOptimizer=AdamOptimizer, Saver=Saver)
+    tf.Session = Session
+    return tf
+
+
+class Record:
+    def __init__(self, names, readers):
+        self.names, self.readers = names, readers
+        self.lines, self.rows, self.row = [], [], {}
+        self.scopes, self.saved, self.runs, self.clips, self.placeholders = [], [], [], [], []
+        self.adam_args = self.minimize = self.model_input = self.model_kwargs = self.inception_kwargs = None
+        self.initialised = False
+        self.fed, self.logits_fed, self.restored, self.converted = [], [], [], []
+
+    def glob(self, pattern):
+        assert pattern == "model/videos/*.mp4"
+        return list(self.names)
+
+    def placeholder(self, p):
+        self.placeholders.append(p)
+        return p
+
+
+def pil_imresize(arr, size, interp="bilinear", mode=None):
+    """scipy.misc.imresize as scipy <= 1.2 published it, for the uint8 RGB frames imageio yields: toimage() takes uint8 data as is,
+    Image.resize((w, h), resample = BILINEAR), fromimage()."""
+    from PIL import Image
+    a = np.asarray(arr)
+    assert a.dtype == np.uint8 and interp == "bilinear" and mode is None
+    return np.asarray(Image.fromarray(a).resize((int(size[1]), int(size[0])), resample=Image.BILINEAR))
+
+
+def run_reference(videos, unreadable, seed, basedir, inception=False):
+    names = ["model/videos/v%02d.mp4" % i for i in range(len(videos))]
+    model = FeatureModel() if inception else OracleModel()
+    rec = Record(names, dict(zip(names, videos)))
+
+    class Reader:
+        def __init__(self, v):
+            self.v = v
+
+        def __len__(self):
+            return len(self.v)
+
+        def get_data(self, j):
+            return self.v[j]
+
+    def get_reader(name, fmt):
+        assert fmt == "ffmpeg"
+        if int(name[-6:-4]) in unreadable:
+            raise IOError("cannot read " + name)
+        return Reader(rec.readers[name])
+
+    class Writer:
+        def __init__(self, name):
+            self.name, self.frames = name, []
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            rec.clips.append((self.name, np.stack(self.frames)))
+            return False
+
+        def append_data(self, f):
+            self.frames.append(np.asarray(f))
+    imageio = types.ModuleType("imageio")
+    imageio.get_reader = get_reader
+    imageio.get_writer = lambda name, mode=None: Writer(name)
+    logger = types.ModuleType("rllab.misc.logger")
+    logger._snapshot_dir = basedir.rstrip("/")
+    logger.log = lambda s: rec.lines.append(s)
+    logger.record_tabular = lambda k, v: rec.row.__setitem__(k, v)
+    logger.dump_tabular = lambda with_prefix=False: (rec.rows.append(dict(rec.row)), rec.row.clear())
+
+    class StubModel:
+        def __init__(self, *a, **k):
+            assert not a
+            rec.model_kwargs = k
+
+        def build(self, x):
+            rec.model_input = x
+            for k in ("loss", "simloss", "recon1", "recon2", "out", "out2"):
+                setattr(self, k, Node(lambda e, k=k: e["res"][k], tag=k))
+
+    class Shaped(Node):
+        def __init__(self, fn, shape):
+            super().__init__(fn)
+            self._shape = shape
+
+        def get_shape(self):
+            return types.SimpleNamespace(as_list=lambda: list(self._shape))
+
+    def inception_v3_fn(images, **k):
+        rec.inception_kwargs = k
+        feat = Shaped(lambda e: front_end(val(images, e)), [3 * B, 2, 2, 8])
+        return Node(lambda e: np.tile(np.arange(1001.0), (3 * B, 1)), tag="logits"), {"Mixed_7c": feat}
+    arm = types.ModuleType("gym.envs.mujoco.arm_shaping")
+    arm.ContextSkipNew = arm.ContextAEReal = arm.ContextAEInception2 = StubModel
+    misc = types.ModuleType("scipy.misc")
+    misc.imresize = pil_imresize
+    misc.imread = lambda name: np.random.default_rng(1).integers(0, 256, (40, 50, 3), dtype=np.uint8)      # 'model/bird.jpg' (:108)
+    stubs = {"tensorflow": make_tf(model, rec), "imageio": imageio, "rllab": types.ModuleType("rllab"), "rllab.misc": types.ModuleType("rllab.misc"),
+             "rllab.misc.logger": logger, "nets": types.ModuleType("nets"), "nets.inception_v3": types.ModuleType("nets.inception_v3"),
+             "gym": types.ModuleType("gym"), "gym.envs": types.ModuleType("gym.envs"), "gym.envs.mujoco": types.ModuleType("gym.envs.mujoco"),
+             "gym.envs.mujoco.arm_shaping": arm, "scipy.misc": misc}
+    stubs["rllab.misc"].logger = logger
+    stubs["nets"].inception_v3 = stubs["nets.inception_v3"]
+    stubs["nets.inception_v3"].inception_v3 = inception_v3_fn
+    stubs["nets.inception_v3"].inception_v3_arg_scope = lambda: "arg_scope"
+    stubs["gym.envs.mujoco"].arm_shaping = arm
+    import scipy
+    saved = {k: sys.modules.get(k) for k in stubs}
+    saved_misc = getattr(scipy, "misc", None)
+    sys.modules.update(stubs)
+    scipy.misc = misc
+    try:
+        path = os.path.join(reference_root(), "scripts", "train_script.py")
+        with open(path) as f:
+            src = f.read()
+        if not inception:
+            # the ONE repair (module docstring): `featreshape`, which :148 reads, is only assigned in the Inception branch (:112) -- a local of
+            # train(), so the other branch dies with UnboundLocalError as written.  The line below is put in front of :148, in memory only.
+            lines_ = src.split("\n")
+            at = [i for i, ln in enumerate(lines_) if ln.lstrip().startswith("nn_err = tf.reduce_sum(") and "featreshape[2]" in ln]
+            assert len(at) == 1, "train_script.py:148 not found"
+            indent = lines_[at[0]][:len(lines_[at[0]]) - len(lines_[at[0]].lstrip())]
+            lines_[at[0]] = indent + "featreshape = tfinput; " + lines_[at[0]].lstrip()       # (same line: the script's line numbers stay)
+            src = "\n".join(lines_)
+        mod = types.ModuleType("ref_train_script")
+        mod.__file__ = path
+        exec(compile(src, path, "exec"), mod.__dict__)
+        np.random.seed(seed)
+        if inception:
+            t = mod.ModelTrainer((H, W), NVIDEOS, NTRAIN, B, "ContextAEInception", NITR, SAVE, NLEN, NSKIP, False, True, STRIDES, KERNELS, FILTERS)
+        else:
+            t = mod.ModelTrainer((H, W), NVIDEOS, NTRAIN, B, "ContextSkipNew", NITR, SAVE, NLEN, NSKIP, True, False, None, None, None)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):                # (:139 prints the classifier's top 20)
+            t.train()
+        after = np.random.randint(1 << 30)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        if saved_misc is not None:
+            scipy.misc = saved_misc
+    return model, rec, after
+
+
+def run_ours(videos, unreadable, seed, basedir, inception=False):
+    model = FakeInceptionTranslator() if inception else OracleModel()
+    lines, clips = [], []
+
+    def reader(i):
+        def f():
+            if i in unreadable:
+                raise IOError("cannot read video %d" % i)
+            return videos[i]
+        return f
+    saved_clip = our_trainer.save_clip
+    our_trainer.save_clip = lambda stem, frames: clips.append((stem, np.asarray(frames).copy()))
+    try:
+        np.random.seed(seed)
+        if inception:
+            t = our_trainer.ModelTrainer((H, W), NVIDEOS, NTRAIN, B, "ContextAEInception", NITR, SAVE, NLEN, NSKIP, False, True, STRIDES, KERNELS, FILTERS,
+                                         videos=[reader(i) for i in range(len(videos))], basedir=basedir, translator=model, log=lines.append)
+        else:
+            t = our_trainer.ModelTrainer((H, W), NVIDEOS, NTRAIN, B, "ContextSkipNew", NITR, SAVE, NLEN, NSKIP, True, False,
+                                         videos=[reader(i) for i in range(len(videos))], basedir=basedir, translator=model, log=lines.append)
+        t.train()
+        after = np.random.randint(1 << 30)
+    finally:
+        our_trainer.save_clip = saved_clip
+    return model, lines, clips, t, after
+
+
+def compare(verbose=False):
+    """Returns a list of (what, ok, detail)."""
+    videos, unreadable = make_videos()
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        rb, ob = os.path.join(d, "ref") + "/", os.path.join(d, "ours") + "/"
+        os.makedirs(rb)
+        rmodel, rec, rafter = run_reference(videos, unreadable, 7, rb)
+        omodel, lines, clips, tr, oafter = run_ours(videos, unreadable, 7, ob)
+
+        def add(what, ok, detail=""):
+            out.append((what, bool(ok), detail))
+        rf = sorted(f for f in os.listdir(rb) if f.startswith("vdata_strike"))
+        of = sorted(f for f in os.listdir(ob) if f.startswith("vdata_strike"))
+        add("saved demo tensor: file name", rf == of and len(rf) == 1, f"{rf} / {of}")
+        a, b = np.load(rb + rf[0]), np.load(ob + of[0])
+        add("saved demo tensor: shape, dtype, bytes", a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a, b), f"{a.shape} {a.dtype} / {b.shape} {b.dtype}")
+        a, b = np.load(rb + "vdata_train.npy"), np.load(ob + "vdata_train.npy")
+        add("vdata_train.npy", a.shape == b.shape and np.array_equal(a, b), str(a.shape))
+        add("optimiser: AdamOptimizer(learning_rate placeholder), TF defaults", rec.adam_args is not None and len(rec.adam_args[0]) == 1 and not rec.adam_args[1]
+            and isinstance(rec.adam_args[0][0], Placeholder) and rec.adam_args[0][0].shape == [], str(rec.adam_args))
+        add("minimize(loss, var_list = TRAINABLE_VARIABLES of 'contextmodel'); model built inside scope 'contextmodel'",
+            rec.minimize[0].tag == "loss" and rec.minimize[1] == ("collection", "trainable_variables", "contextmodel") and rec.scopes == ["contextmodel"], str(rec.scopes))
+        add("image placeholder float32 [3, B, H, W, 3] named 'x'", any(p.name == "x" and p.dtype == "float32" and tuple(p.shape) == (3, B, H, W, 3) for p in rec.placeholders))
+        # the reference fetches a clip twice on the same batch (out, then out2: :191-192); the trainer evaluates it once and reads both
+        assert len(rec.runs) == len(rmodel.calls)
+        twice = [i for i, (_, f) in enumerate(rec.runs) if f[-1] == "out2"]
+        add("a clip's second fetch (out2) is fed the batch of its first (out)", all(rec.runs[i - 1][1][-1] == "out" and np.array_equal(rmodel.calls[i][2], rmodel.calls[i - 1][2])
+                                                                                  for i in twice), f"{len(twice)} clips")
+        rcalls = [c for i, c in enumerate(rmodel.calls) if i not in set(twice)]
+        add("number of distinct session runs", len(rcalls) == len(omodel.calls), f"{len(rcalls)} / {len(omodel.calls)}")
+        same = len(rcalls) == len(omodel.calls) and all(x[0] == y[0] and x[1] == y[1] and x[2].shape == y[2].shape and np.array_equal(x[2], y[2])
+                                                        for x, y in zip(rcalls, omodel.calls))
+        add("every fed batch [src, ctx, tgt] in order, kind and learning rate, bit for bit", same,
+            f"{sum(1 for c in rmodel.calls if c[0] == 'train')} optimiser runs at lr {sorted({c[1] for c in rmodel.calls if c[0] == 'train'})}, "
+            f"{sum(1 for c in rmodel.calls if c[0] == 'eval')} evaluation runs")
+        kinds = {}
+        for k, f in rec.runs:
+            kinds[(k, f)] = kinds.get((k, f), 0) + 1
+        want = {("train", ("optimizer", "loss", "simloss", "recon1", "recon2", "expr")): (NITR - 1) // 4, ("train", ("optimizer",)): NITR - 1 - (NITR - 1) // 4,
+                ("eval", ("loss", "simloss", "recon1", "recon2", "expr")): 2, ("eval", ("loss", "recon1", "recon2", "out")): 20,
+                ("eval", ("loss", "recon1", "recon2", "out2")): 20}
+        add("fetch lists of the four sess.run sites and how often each runs", kinds == want, str(kinds))
+        nkept = np.load(rb + rf[0]).shape[1]
+        start = rec.lines.index("%s %s" % (NTRAIN, nkept - NTRAIN))
+        ostart = lines.index(rec.lines[start])
+        add("log lines from the split on (train logs every 4th iteration, validation 'E' lines)", rec.lines[start:] == lines[ostart:], f"{len(rec.lines) - start} lines")
+        add("checkpoint paths (relative to the snapshot directory); variable names under 'contextmodel/'",
+            [os.path.relpath(p, rb) for p in rec.saved] == [os.path.relpath(p, ob) for p, _ in omodel.saved] and all(pre == "contextmodel/" for _, pre in omodel.saved),
+            str([os.path.relpath(p, rb) for p in rec.saved]))
+        for it in (20, 40):
+            add(f"{it}/validloss.npy", np.array_equal(np.load(f"{rb}{it}/validloss.npy"), np.load(f"{ob}{it}/validloss.npy")))
+        rc = [(os.path.relpath(n, rb), f) for n, f in rec.clips]
+        oc = [(os.path.relpath(n, ob) + ".gif", f) for n, f in clips]
+        add("clip names and uint8 frames handed to the GIF writer", len(rc) == len(oc) == 40 and all(x[0] == y[0] and x[1].dtype == y[1].dtype == np.uint8 and np.array_equal(x[1], y[1])
+                                                                                                   for x, y in zip(rc, oc)), f"{len(rc)} clips of {rc[0][1].shape}")
+        import csv
+        with open(ob + "progress.csv") as f:
+            table = list(csv.DictReader(f))
+        add("tabular rows (Iteration, Loss, Sim, R1, R2, NNErr)", len(table) == len(rec.rows) and all(
+            all(float(t[k]) == float(r[k]) for k in ("Iteration", "Loss", "Sim", "R1", "R2", "NNErr")) for t, r in zip(table, rec.rows)), f"{len(rec.rows)} rows")
+        add("parameters after the run (same oracle, same batches)", all(np.array_equal(rmodel.p[k], omodel.p[k]) for k in rmodel.p))
+        add("np.random stands where the reference leaves it", rafter == oafter)
+        if verbose:
+            print("reference log, video phase:", rec.lines[:start])
+            print("ours:", lines[:ostart])
+    return out
+
+
+def compare_inception(verbose=False):
+    """The Inception branch (:98-114, :135-139) -- the one that runs AS WRITTEN, no repair: uint8 frames (rescale False, no black-frame rule),
+    the uint8 placeholder and its preprocessing chain, inception_v3's arguments, Mixed_7c reshaped to [3, B, h, w, c] as the model's input, the
+    model's strides / kernels / filters, the restore + classifier sanity run, no clips -- against ModelTrainer(inception=True) on a translator
+    with InceptionTranslator's surface."""
+    videos, unreadable = make_videos()
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        rb, ob = os.path.join(d, "ref") + "/", os.path.join(d, "ours") + "/"
+        os.makedirs(rb)
+        rmodel, rec, rafter = run_reference(videos, unreadable, 11, rb, inception=True)
+        omodel, lines, clips, tr, oafter = run_ours(videos, unreadable, 11, ob, inception=True)
+
+        def add(what, ok, detail=""):
+            out.append((what, bool(ok), detail))
+        rf = sorted(f for f in os.listdir(rb) if f.startswith("vdata_strike"))
+        of = sorted(f for f in os.listdir(ob) if f.startswith("vdata_strike"))
+        add("saved demo tensor: file name", rf == of and len(rf) == 1, f"{rf} / {of}")
+        a, b = np.load(rb + rf[0]), np.load(ob + of[0])
+        add("saved demo tensor: uint8, the black-frame video kept, bytes", a.dtype == b.dtype == np.uint8 and a.shape == b.shape and np.array_equal(a, b), f"{a.shape} {a.dtype}")
+        a2, b2 = np.load(rb + "vdata_train.npy"), np.load(ob + "vdata_train.npy")
+        add("vdata_train.npy", a2.shape == b2.shape and np.array_equal(a2, b2), str(a2.shape))
+        add("image placeholder uint8 [3, B, H, W, 3] named 'image'; converted from uint8", any(p.name == "image" and p.dtype == "uint8" and tuple(p.shape) == (3, B, H, W, 3)
+                                                                                              for p in rec.placeholders) and set(rec.converted) == {np.dtype(np.uint8)})
+        add("inception_v3(images, num_classes=1001, is_training=False, dropout_keep_prob=1.0)",
+            rec.inception_kwargs == dict(num_classes=1001, is_training=False, dropout_keep_prob=1.0), str(rec.inception_kwargs))
+        add("model(strides, kernels, filters) built on Mixed_7c reshaped [3, B, h, w, c] inside scope 'contextmodel'",
+            rec.model_kwargs == dict(strides=STRIDES, kernels=KERNELS, filters=FILTERS) and rec.scopes == ["contextmodel"], str(rec.model_kwargs))
+        add("front end restored from model/inception_v3.ckpt (variables_to_restore), classifier run on [[bird] * B] * 3",
+            rec.restored == [(("variables_to_restore",), "model/inception_v3.ckpt")] and len(rec.logits_fed) == 1 and rec.logits_fed[0].shape == (3, B, H, W, 3), str(rec.restored))
+        add("number of session runs", len(rec.fed) == len(omodel.fed), f"{len(rec.fed)} / {len(omodel.fed)}")
+        kinds = [k for k, _ in rec.runs]
+        add("every fed uint8 batch [src, ctx, tgt] in order and kind, bit for bit", len(rec.fed) == len(omodel.fed) and all(
+            k == y[0] and x.dtype == np.uint8 and x.shape == y[1].shape and np.array_equal(x, y[1]) for k, x, y in zip(kinds, rec.fed, omodel.fed)),
+            f"{kinds.count('train')} optimiser runs, {kinds.count('eval')} evaluation runs")
+        add("no clips in the Inception branch", not rec.clips and not clips)
+        start = rec.lines.index("%s %s" % (NTRAIN, a.shape[1] - NTRAIN))
+        ostart = lines.index(rec.lines[start])
+        add("log lines from the split on (nn_err on the tgt feature maps)", rec.lines[start:] == lines[ostart:], f"{len(rec.lines) - start} lines")
+        add("checkpoint paths; variable names under 'contextmodel/'", [os.path.relpath(p, rb) for p in rec.saved] == [os.path.relpath(p, ob) for p, _ in omodel.saved]
+            and len(rec.saved) == 2 and all(pre == "contextmodel/" for _, pre in omodel.saved), str([os.path.relpath(p, rb) for p in rec.saved]))
+        for it in (20, 40):
+            add(f"{it}/validloss.npy", np.array_equal(np.load(f"{rb}{it}/validloss.npy"), np.load(f"{ob}{it}/validloss.npy")))
+        import csv
+        with open(ob + "progress.csv") as f:
+            table = list(csv.DictReader(f))
+        add("tabular rows", len(table) == len(rec.rows) == 2 and all(all(float(t[k]) == float(r[k]) for k in ("Iteration", "Loss", "Sim", "R1", "R2", "NNErr"))
+                                                                     for t, r in zip(table, rec.rows)), f"{len(rec.rows)} rows")
+        add("np.random stands where the reference leaves it", rafter == oafter)
+        if verbose:
+            print("reference log, video phase:", rec.lines[:start])
+            print("ours:", lines[:ostart])
+    return out
+
+
+def main():
+    if not os.path.isdir(reference_root()):
+        print("no reference tree at", reference_root(), "- nothing checked")
+        return 2
+    bad = 0
+    for title, fn in (("ContextSkipNew branch (one repair: featreshape = tfinput in front of :148)", compare), ("Inception branch (as written)", compare_inception)):
+        print("==", title)
+        res = fn("-v" in sys.argv)
+        for what, ok, detail in res:
+            print(f"{'OK     ' if ok else 'DIFFERS'}  {what}" + (f"   [{detail}]" if detail else ""))
+        bad += not all(ok for _, ok, _ in res)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -13,6 +13,7 @@ if GOLD not in sys.path:
     sys.path.insert(0, GOLD)
 import check_reference_inception as cri  # noqa: E402
 import check_reference_reward as crr  # noqa: E402
+import check_reference_trainer as crt  # noqa: E402
 import check_reference_wiring as crw  # noqa: E402
 import tf_standin  # noqa: E402
 
@@ -50,6 +51,37 @@ def test_reference_process_samples_equals_the_reward_hook(name):
     worst, calls = crr.CASES[name]()
     assert worst <= crr.BAR, worst
     assert ("TRANSLATED_Z", "OUT") in calls and ("INPUT_Z", "IMAGE_TRANS") in calls
+
+
+def test_reference_train_script_equals_the_trainer():
+    """The reference's own `ModelTrainer.train()` (scripts/train_script.py:28-204; one in-memory repair of its unassigned `featreshape`, see
+    the check's docstring) executed on stand-ins -- synthetic videos behind imageio, a deferred-graph tensorflow whose session is answered by the
+    oracle -- against trainer.ModelTrainer(videos=...): the saved demo tensor byte for byte (video shuffle, 51-frame rule, nskip frames,
+    Pillow's bilinear resize, black-frame drop, the nvideos cap), every batch of every sess.run in order, the optimiser's construction, log
+    lines, checkpoints, clip frames, tabular rows and the final np.random state."""
+    res = crt.compare()
+    assert len(res) >= 18
+    assert all(ok for _, ok, _ in res), [(w, d) for w, ok, d in res if not ok]
+
+
+def test_reference_train_script_inception_branch_equals_the_trainer():
+    """The same script's Inception branch (:98-114, :135-139), which runs AS WRITTEN: uint8 frames without the black-frame rule, the uint8
+    placeholder and preprocessing chain, inception_v3's arguments, the model's strides / kernels / filters on Mixed_7c reshaped [3, B, h, w, c],
+    the restore and the classifier run, no clips -- against ModelTrainer(inception=True): every fed uint8 batch, logs, checkpoints, tabular rows."""
+    res = crt.compare_inception()
+    assert len(res) >= 16
+    assert all(ok for _, ok, _ in res), [(w, d) for w, ok, d in res if not ok]
+
+
+def test_the_trainer_check_sees_a_swapped_slot(monkeypatch):
+    """Negative control: a trainer that feeds [tgt, ctx, src] instead of [src, ctx, tgt] must fail the batch comparison (and only what
+    follows from it)."""
+    from imitation_from_observation_amd import trainer
+    real = trainer.ModelTrainer._batch
+    monkeypatch.setattr(trainer.ModelTrainer, "_batch", lambda self, data, cs, ct: real(self, data, cs, ct)[::-1])
+    res = {w: ok for w, ok, _ in crt.compare()}
+    assert not res["every fed batch [src, ctx, tgt] in order, kind and learning rate, bit for bit"]
+    assert res["saved demo tensor: shape, dtype, bytes"] and res["np.random stands where the reference leaves it"]
 
 
 def test_the_check_sees_a_wiring_error(monkeypatch):
