@@ -262,7 +262,12 @@ def make_tf(model, record):
         def restore(self, sess, path):
             record.restored.append((self.args, path))
 
+    tf.ConfigProto = lambda: types.SimpleNamespace(gpu_options=types.SimpleNamespace(allow_growth=False))
+
     class Session:
+        def __init__(self, config=None):
+            record.session_config = config
+
         def run(self, fetches, feed_dict=None):
             single = not isinstance(fetches, (list, tuple))
             fl = [fetches] if single else list(fetches)
@@ -302,6 +307,7 @@ class Record:
         self.adam_args = self.minimize = self.model_input = self.model_kwargs = self.inception_kwargs = None
         self.initialised = False
         self.fed, self.logits_fed, self.restored, self.converted = [], [], [], []
+        self.session_config = None
 
     def glob(self, pattern):
         assert pattern == "model/videos/*.mp4"
