@@ -73,6 +73,32 @@ def test_reference_train_script_inception_branch_equals_the_trainer():
     assert all(ok for _, ok, _ in res), [(w, d) for w, ok, d in res if not ok]
 
 
+def test_the_reference_launchers_construct_the_trainer():
+    """sandbox/andrew/run_train_*.py, the callers of scripts/train_script.py: the `ModelTrainer(...)` call of each launcher, read from the file
+    (ast; nothing is executed -- the launchers start EC2 jobs), constructs trainer.ModelTrainer with the same keywords and values.  The throw
+    launcher omits nlen / nskip, which the reference's __init__ requires (train_script.py:29-30): a TypeError there, and here."""
+    import ast
+    import glob
+    from imitation_from_observation_amd.trainer import ModelTrainer
+    seen = {}
+    for path in sorted(glob.glob(os.path.join(crw.reference_root(), "sandbox", "andrew", "run_train_*.py"))):
+        with open(path) as f:
+            tree = ast.parse(f.read())
+        calls = [n for n in ast.walk(tree) if isinstance(n, ast.Call) and getattr(n.func, "id", "") == "ModelTrainer"]
+        assert len(calls) == 1 and not calls[0].args, path
+        kw = {k.arg: ast.literal_eval(k.value) for k in calls[0].keywords}
+        seen[os.path.basename(path)] = kw
+        if "nlen" in kw:
+            t = ModelTrainer(**kw)
+            assert (t.idims, t.batch_size, t.model, t.nlen, t.nskip) == (tuple(kw["idims"]), kw["batch_size"], kw["model"], kw["nlen"], kw["nskip"])
+            assert t.inception == kw.get("inception", False) and t.rescale == kw.get("rescale", True) and t.filters == kw.get("filters")
+        else:
+            with pytest.raises(TypeError):
+                ModelTrainer(**kw)
+    assert {"run_train_strike.py", "run_train_strike_inception.py", "run_train_throw.py"} <= set(seen)
+    assert seen["run_train_strike.py"]["batch_size"] == 100 and seen["run_train_strike_inception.py"]["filters"] == [1024, 1024, 512, 512]
+
+
 def test_the_trainer_check_sees_a_swapped_slot(monkeypatch):
     """Negative control: a trainer that feeds [tgt, ctx, src] instead of [src, ctx, tgt] must fail the batch comparison (and only what
     follows from it)."""
