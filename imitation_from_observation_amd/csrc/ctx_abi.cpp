@@ -323,11 +323,30 @@ int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ct
     uint8_t* u_ctx = h->u8 + B * npi;
     HIP_TRY(h, hipMemcpyAsync(u_src, src, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(u_ctx, ctx0, (size_t)(ctx_batched ? B : 1) * npi, hipMemcpyHostToDevice, h->stream));
-    u8_to_f32(h->stream, u_src, h->img + B * npi, B * npi);
     h->ctx_single = !ctx_batched;                 // one context frame: encoded once, read by every row (forward)
-    u8_to_f32(h->stream, u_ctx, h->img + 2 * B * npi, (ctx_batched ? B : 1) * npi);
+    u8_to_f32(h->stream, u_src, h->img + B * npi, (B + (ctx_batched ? B : 1)) * npi);      // [src | ctx] are adjacent in both buffers: one launch
     return translate_tail(h, B, pred, feat);
 }
+
+// image_trans of uint8 frames ON THE HOST: the 256 values of prep_u8 (kernels.hip: x * (1/255), - 0.5, * 2.0 as three separately rounded f32
+// operations, base.py:116-119) from a table -- bit-identical to what u8_to_f32_kernel writes.  ctx_encode hands `frames_f32` back this way
+// at the reward hook's call sizes: the conversion runs while the device encodes, and the 1.2 MB download of the batch of 25 (a pageable
+// copy, ~40 us of a 0.27 ms call) is not made.
+static void host_prep_u8(const uint8_t* in, float* out, size_t n) {
+    static const struct Lut {
+        float v[256];
+        Lut() {
+#pragma clang fp contract(off)
+            for (int x = 0; x < 256; ++x) {
+                volatile float scaled = (float)x * (1.0f / 255.0f);
+                volatile float centred = scaled - 0.5f;
+                v[x] = centred * 2.0f;
+            }
+        }
+    } lut;
+    for (size_t i = 0; i < n; ++i) out[i] = lut.v[in[i]];
+}
+constexpr size_t HOST_PREP_MAX = 1u << 20;        // elements (64 frames of 64x64x3): beyond, the device's copy is the faster source
 
 int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32) {
     TRY(check_B(h, B));
@@ -338,9 +357,11 @@ int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* 
     HIP_TRY(h, hipMemcpyAsync(h->u8, frames, (size_t)B * npi, hipMemcpyHostToDevice, h->stream));
     u8_to_f32(h->stream, h->u8, h->img + B * npi, B * npi);
     TRY(forward_inference(h, B, MODE_ENCODE));
+    const bool on_host = frames_f32 && (size_t)B * npi <= HOST_PREP_MAX;
+    if (on_host) host_prep_u8(frames, frames_f32, (size_t)B * npi);                      // (the device is busy with the launches above)
     if (feat) HIP_TRY(h, hipMemcpy2DAsync(feat, h->F * sizeof(float), h->Z + 2ll * B * h->Fp, h->Fp * sizeof(float), h->F * sizeof(float), B,
                                          hipMemcpyDeviceToHost, h->stream));
-    if (frames_f32) TRY(copy_d2h(h, frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float)));
+    if (frames_f32 && !on_host) TRY(copy_d2h(h, frames_f32, h->img + B * npi, (size_t)B * npi * sizeof(float)));
     h->last_B = 0;
     return finish(h);
 }

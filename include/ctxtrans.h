@@ -180,7 +180,8 @@ int ctx_init_params(ctx_handle* h, uint64_t seed);
 int ctx_translate(ctx_handle* h, const uint8_t* src, const uint8_t* ctx0, int ctx_batched, int B,
                   float* pred, float* feat);
 /* frames [B,H,W,3] uint8 -> feat [B,featsize] = model.input_z; frames_f32 (nullable) [B,H,W,3] =
- * image_trans[0] = (x/255 - 0.5)*2. */
+ * image_trans[0] = (x/255 - 0.5)*2 -- the device's bits either way: up to 2^20 elements (the hook's batch of 25 and a few paths) they are written
+ * by the host from the 256-entry table of the same three f32 operations while the device encodes (no download), beyond that copied back. */
 int ctx_encode(ctx_handle* h, const uint8_t* frames, int B, float* feat, float* frames_f32);
 /* The same two fetches on float inputs [B,H,W,C]: frames already scaled to [-1,1], or -- for
  * CTX_VARIANT_INCEPTION2, where image_trans IS the feature tensor (base.py:127-132) -- Mixed_7c feature maps. */
