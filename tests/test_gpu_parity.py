@@ -265,6 +265,22 @@ def test_inference_call_sites_match_oracle(T):
 
 
 # ------------------------------------------------------------------------------- vs the golden vectors
+def test_encode_image_trans_host_table_equals_the_device_copy(T):
+    """ctx_encode's second fetch, image_trans (base.py:234-235): up to 2^20 elements the host writes it from the 256-entry table of prep_u8 while
+    the device encodes, beyond that it is copied back from the device -- the same bits from both, and the oracle's (three rounded f32 ops)."""
+    H = W = 64
+    rng = np.random.default_rng(12)
+    fr = rng.integers(0, 256, (96, H, W, 3), dtype=np.uint8)
+    fr[0, 0, :86, :] = np.arange(258, dtype=np.uint8).reshape(86, 3)               # every uint8 value occurs
+    with T(H, W, 32, 64, max_batch=96) as tr:
+        tr.init_params(2)
+        f_dev, x_dev = (a.copy() for a in tr.encode(fr))                           # 96 * 12288 = 1.18 M elements: the device's copy
+        f_host, x_host = (a.copy() for a in tr.encode(fr[:80]))                    # 0.98 M: the host's table
+    np.testing.assert_array_equal(x_host, x_dev[:80])
+    np.testing.assert_array_equal(x_dev, o.preprocess_u8(fr))
+    assert relmax(f_host, f_dev[:80]) < 1e-5
+
+
 @pytest.mark.parametrize("path", GOLD, ids=os.path.basename)
 def test_golden_vectors(T, path):
     z, cfg, p = load_golden(path)
