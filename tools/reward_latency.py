@@ -13,7 +13,9 @@ for label, mk, H, W in (("ContextSkipNew 64x64", lambda: Translator(64, 64, 64, 
     tr = mk()
     tr.init_params(0)
     x = rng.integers(0, 256, (25, H, W, 3), dtype=np.uint8)
-    for name, fn in (("encode", lambda: tr.encode(x)), ("translate", lambda: tr.translate(x, x[0]))):
+    # "path cost": the whole of base.py:232-249 for one path on the device (ctx_reward_costs: encoder + both distances; 25 floats come back)
+    tr.reward_set_cache(0, rng.standard_normal((25, tr.featsize)).astype(np.float32), rng.uniform(-1, 1, (25, H, W, 3)).astype(np.float32))
+    for name, fn in (("encode", lambda: tr.encode(x)), ("translate", lambda: tr.translate(x, x[0])), ("path cost", lambda: tr.reward_costs(0, x, 0.1))):
         for _ in range(5):
             fn()
         ts = []
