@@ -271,7 +271,7 @@ def test_encode_image_trans_host_table_equals_the_device_copy(T):
     H = W = 64
     rng = np.random.default_rng(12)
     fr = rng.integers(0, 256, (96, H, W, 3), dtype=np.uint8)
-    fr[0, 0, :86, :] = np.arange(258, dtype=np.uint8).reshape(86, 3)               # every uint8 value occurs
+    fr[0].reshape(-1)[:256] = np.arange(256, dtype=np.uint8)                        # every uint8 value occurs
     with T(H, W, 32, 64, max_batch=96) as tr:
         tr.init_params(2)
         f_dev, x_dev = (a.copy() for a in tr.encode(fr))                           # 96 * 12288 = 1.18 M elements: the device's copy
